@@ -1,0 +1,302 @@
+/*
+ * pathtracer_amd.h — C ABI of the MI355X-native path-tracing hot path.
+ *
+ * This is the drop-in boundary that replaces src/renderer of Dolfun/pathtracer: the
+ * Vulkan device bring-up, the descriptor/pipeline plumbing and the single compute
+ * dispatch of src/renderer/shaders/main.comp.  Every entry point names the reference
+ * interface it stands in for (paths relative to the reference repository root).
+ *
+ * Conventions
+ *   - plain C, no exceptions cross the boundary: every call returns PT_OK (0) or a
+ *     negative pt_status; pt_last_error() gives the text for the last failure
+ *     (the reference throws std::runtime_error / vk::SystemError and main() prints
+ *     them, src/main.cc:86-90).
+ *   - all inputs are BORROWED for the duration of the call and never mutated; all
+ *     outputs are written into CALLER-OWNED buffers (the reference returns a pointer
+ *     into memory of an already destroyed RenderJob, src/renderer/renderer.cc:186-193).
+ *   - every struct below is byte-for-byte the layout the reference host hands to its
+ *     shader, so reference-packed data is accepted verbatim.
+ *   - a pt_ctx is bound to one GPU and is not thread-safe (the reference is single
+ *     threaded with one queue, src/renderer/render_job.cc:819-834).
+ */
+#ifndef PATHTRACER_AMD_H
+#define PATHTRACER_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PT_API __attribute__((visibility("default")))
+
+typedef enum pt_status {
+  PT_OK = 0,
+  PT_ERR_INVALID = -1,   /* bad argument / inconsistent scene */
+  PT_ERR_DEVICE = -2,    /* HIP runtime error */
+  PT_ERR_NO_SCENE = -3,  /* render before upload */
+  PT_ERR_LIMIT = -4      /* a stated limit exceeded (stack depth, counts) */
+} pt_status;
+
+/* ------------------------------------------------------------------ scene.h PODs */
+
+/* Scene::Vertex, src/scene.h:9-16 (60 bytes, no padding) */
+typedef struct pt_vertex {
+  float position[3];
+  float normal[3];
+  float tangent[3];
+  float bitangent[3];
+  float texcoord[2];
+  int32_t material_index;
+} pt_vertex;
+
+/* Scene::Material, src/scene.h:20-32 == GLSL `Material`, main.comp:42-58 (64 bytes) */
+typedef struct pt_material {
+  float base_color_factor[4];
+  int32_t base_color_texture_index;
+  float metallic_factor;
+  float roughness_factor;
+  int32_t metallic_roughness_texture_index;
+  float normal_scale;
+  int32_t normal_texture_index;
+  float occlusion_strength;
+  int32_t occlusion_texture_index;
+  float emissive_factor[3];
+  int32_t emissive_texture_index;
+} pt_material;
+
+/* Scene::DirectionalLight, src/scene.h:57-61 (alignas(16) -> 32 bytes) */
+typedef struct pt_directional_light {
+  float color[3];
+  float intensity;
+  float direction[3];
+  float _pad;
+} pt_directional_light;
+
+/* Scene::PointLight, src/scene.h:63-67 (32 bytes) */
+typedef struct pt_point_light {
+  float color[3];
+  float intensity;
+  float position[3];
+  float _pad;
+} pt_point_light;
+
+/* Scene::SamplerFilter_t / SamplerWarp_t, src/scene.h:34-40 */
+enum { PT_FILTER_NEAREST = 0, PT_FILTER_LINEAR = 1 };
+enum { PT_WRAP_CLAMP_TO_EDGE = 0, PT_WRAP_MIRRORED_REPEAT = 1, PT_WRAP_REPEAT = 2 };
+
+/* Scene::Sampler, src/scene.h:42-45 */
+typedef struct pt_sampler {
+  int32_t mag_filter, min_filter;
+  int32_t wrap_s, wrap_t;
+} pt_sampler;
+
+/* Scene::Texture, src/scene.h:52-55 */
+typedef struct pt_texture {
+  int32_t sampler_index;
+  int32_t image_index;
+} pt_texture;
+
+/* Scene::Image, src/scene.h:47-50 — always RGBA8 (gltf_loader.cc:280-282) */
+typedef struct pt_image {
+  uint32_t width, height;
+  const uint8_t* rgba8; /* width*height*4 bytes, row-major, row 0 first */
+} pt_image;
+
+/* Scene::Camera, src/scene.h:69-73; `lookat` is a DIRECTION (render_job.cc:851) */
+typedef struct pt_camera {
+  float position[3];
+  float lookat[3];
+  float vertical_fov;
+} pt_camera;
+
+/* BVHNode, src/bvh/bvh.h:36-41 (36 bytes) */
+typedef struct pt_bvh_node {
+  float aabb_min[3];
+  float aabb_max[3];
+  uint32_t left_child_index;
+  uint32_t begin_index;
+  uint32_t triangle_count;
+} pt_bvh_node;
+
+/* ------------------------------------------------------- render_job.h device PODs */
+
+/* PackedVertexData, src/renderer/render_job.h:7-13 == GLSL `Vertex`, main.comp:25-33 */
+typedef struct pt_packed_vertex {
+  float position[4];
+  float normal_and_texcoord_u[4];
+  float tangent_and_texcoord_v[4];
+  float bitangent[3];
+  int32_t material_index;
+} pt_packed_vertex;
+
+/* PackedBVHNode, src/renderer/render_job.h:15-20 == GLSL `BVHNode`, main.comp:35-40 */
+typedef struct pt_packed_bvh_node {
+  float aabb_min[3];
+  uint32_t left_or_begin;
+  float aabb_max[3];
+  uint32_t triangle_count;
+} pt_packed_bvh_node;
+
+/* PushConstants, src/renderer/render_job.h:22-38 == main.comp:123-130 (96 bytes) */
+typedef struct pt_push_constants {
+  float camera_position[3];   float _p0;
+  float pixel_delta_u[3];     float _p1;
+  float pixel_delta_v[3];     float _p2;
+  float corner_pixel_pos[3];  float _p3;
+  uint32_t resolution_x, resolution_y;
+  uint32_t seed;
+  uint32_t sample_count;
+  float bg_color[3];
+  uint32_t emissive_triangle_count;
+} pt_push_constants;
+
+/* RenderConfig, src/renderer/renderer.h:16-20 */
+typedef struct pt_render_config {
+  uint32_t resolution_x, resolution_y;
+  uint32_t sample_count;
+  float bg_color[3];
+} pt_render_config;
+
+/*
+ * Everything RenderJob binds for the dispatch (descriptor bindings 0-7 and the
+ * specialization constants, src/renderer/render_job.cc:33-40, 462-521, 563-570).
+ */
+typedef struct pt_scene_desc {
+  uint32_t triangle_count;
+  const float* vertex_positions;              /* binding 0: vec4 x 3 x triangle_count        */
+  const pt_packed_vertex* packed_vertex_data; /* binding 1: 3 x triangle_count               */
+  const pt_packed_bvh_node* bvh_nodes;        /* binding 2                                   */
+  uint32_t bvh_node_count;
+  uint32_t bvh_max_depth;                     /* specialization constant 5                   */
+  const uint32_t* emissive_triangles;         /* binding 3 (may be NULL when count is 0)     */
+  uint32_t emissive_triangle_count;
+  const pt_material* materials;               /* binding 4, specialization constant 2        */
+  uint32_t material_count;
+  const pt_directional_light* directional_lights; /* binding 5                               */
+  uint32_t directional_light_count;           /* spec constant 3: array size - 1 (the trailing dummy excluded) */
+  const pt_point_light* point_lights;         /* binding 6                                   */
+  uint32_t point_light_count;                 /* spec constant 4: array size - 1             */
+  const pt_texture* textures;                 /* binding 7: combined image samplers          */
+  uint32_t texture_count;
+  const pt_image* images;
+  uint32_t image_count;
+  const pt_sampler* samplers;
+  uint32_t sampler_count;
+} pt_scene_desc;
+
+/* The push-constant block plus the build-only fields the reference has no place for. */
+typedef struct pt_render_params {
+  pt_push_constants pc; /* pc.seed is explicit (the reference draws it from std::random_device, render_job.cc:841-844) */
+  uint32_t rank;        /* sample-split data parallelism: this GPU renders strata   */
+  uint32_t num_ranks;   /* [rank*n*n/num_ranks, (rank+1)*n*n/num_ranks); 0 or 1 = all */
+  uint32_t flags;       /* reserved, 0 */
+} pt_render_params;
+
+/* Work counters of one render, SURVEY.md §8d definitions. */
+typedef struct pt_stats {
+  uint64_t paths;          /* trace() calls (camera samples)                               */
+  uint64_t rays;           /* ray_scene_intersect calls: closest-hit + every shadow-walk step */
+  uint64_t node_visits;    /* inner-node visits (two child boxes tested each)              */
+  uint64_t tri_tests;      /* ray_triangle_intersect calls                                 */
+  uint64_t hits_shaded;    /* get_interpolated_data calls (shaded hits + shadow-walk steps + area-light samples) */
+  uint64_t texture_taps;   /* texture() calls with index != -1                             */
+  uint64_t shaded_vertices;/* path vertices run through the BRDF/light-sampling block      */
+  uint64_t nan_samples;    /* samples dropped by the NaN filter (main.comp:608-609)        */
+  uint64_t iterations;     /* wavefront iterations launched                                */
+  double   render_ms;      /* device time of the render loop (HIP events)                  */
+  double   trace_ms;       /* ... spent in the two traversal kernels (extend + shadow), when PT_FLAG_TIME_KERNELS */
+  double   shade_ms;       /* ... spent in the shade kernel, when PT_FLAG_TIME_KERNELS     */
+  double   upload_ms;      /* last pt_upload_scene H2D time                                */
+  double   download_ms;    /* last D2H of the outputs                                      */
+} pt_stats;
+
+#define PT_FLAG_TIME_KERNELS 1u /* bracket every kernel with HIP events (serialises; for profiling) */
+
+typedef struct pt_ctx pt_ctx;
+
+/* ------------------------------------------------------------------- device side */
+
+/* list_devices(), src/renderer/renderer.h:55, renderer.cc:196-213 */
+PT_API int pt_device_count(void);
+PT_API int pt_device_name(int device, char* out, size_t out_size);
+
+/* Renderer::Renderer(device_index), src/renderer/renderer.h:24; device < 0 picks GPU 0
+ * (the reference's -1 picks the first discrete GPU, renderer.cc:58-70). */
+PT_API pt_ctx* pt_create(int device);
+PT_API void pt_destroy(pt_ctx* ctx);
+
+/* Text of the last error on ctx (or of the last failed pt_create when ctx is NULL). */
+PT_API const char* pt_last_error(const pt_ctx* ctx);
+
+/* RenderJob ctor's staging half: create_buffers / stage_* / copy_scene_data_to_device,
+ * src/renderer/render_job.cc:33-51, 689-758.  Copies the scene into HBM (re-laid-out
+ * for the kernels); the caller's arrays are not referenced after return. */
+PT_API int pt_upload_scene(pt_ctx* ctx, const pt_scene_desc* scene);
+
+/* RenderJob::render() + dispatch_compute_shader + copy_result_to_host,
+ * src/renderer/render_job.cc:760-834: runs main.comp's work for every pixel and
+ * returns the rgba8 image (resolution_x*resolution_y*4 bytes) in rgba8_out.
+ * Optional build-only outputs (NULL to skip): accum_out = 4 floats per pixel
+ * (sum R, sum G, sum B over the valid samples, valid-sample count);
+ * primary_id_out = triangle index hit by the pixel's first camera ray
+ * (0xFFFFFFFF on a miss); stats_out. */
+PT_API int pt_render(pt_ctx* ctx, const pt_render_params* params,
+                     uint8_t* rgba8_out, float* accum_out,
+                     uint32_t* primary_id_out, pt_stats* stats_out);
+
+/* Multi-GPU halves of pt_render (no counterpart in the reference, which is single
+ * device): render this rank's strata into a DEVICE accumulator (float4 per pixel,
+ * overwritten), to be sum-reduced over ranks by the caller (RCCL), then resolved.
+ * `stream` is a hipStream_t (NULL = the context's own stream). Both are asynchronous
+ * with respect to the host only as far as the stream is; pt_render_accum_device
+ * itself polls the device for completion of the wavefront loop before returning. */
+PT_API int pt_render_accum_device(pt_ctx* ctx, const pt_render_params* params,
+                                  float* accum_dev, uint32_t* primary_id_dev,
+                                  void* stream, pt_stats* stats_out);
+/* main.comp:616-619: divide by the valid-sample count, gamma, rgba8 store. */
+PT_API int pt_resolve_device(pt_ctx* ctx, const float* accum_dev, uint32_t pixel_count,
+                             uint8_t* rgba8_dev, void* stream);
+
+/* --------------------------------------------------------------------- host side */
+
+/* build_bvh(Scene&, bin_count, depth&), src/bvh/bvh.h:42, bvh.cc:161-169.
+ * `triangles` (3 x uint32 per triangle) is permuted IN PLACE exactly as the reference
+ * permutes scene.triangles (bvh.cc:66).  nodes_out must hold 2*triangle_count entries;
+ * *node_count_out receives the used count. Bit-exact restatement, built with
+ * -ffp-contract=off. */
+PT_API int pt_build_bvh(const pt_vertex* vertices, uint32_t vertex_count,
+                        uint32_t* triangles, uint32_t triangle_count,
+                        uint32_t bin_count,
+                        pt_bvh_node* nodes_out, uint32_t* node_count_out,
+                        uint32_t* depth_out);
+
+/* RenderJob::process_scene(), src/renderer/render_job.cc:76-121.  Output capacities:
+ * vertex_positions_out 12 floats/triangle, packed_vertex_out 3/triangle,
+ * emissive_out triangle_count entries, packed_nodes_out node_count entries. */
+PT_API int pt_process_scene(const pt_vertex* vertices, uint32_t vertex_count,
+                            const uint32_t* triangles, uint32_t triangle_count,
+                            const pt_material* materials, uint32_t material_count,
+                            const pt_bvh_node* nodes, uint32_t node_count,
+                            float* vertex_positions_out,
+                            pt_packed_vertex* packed_vertex_out,
+                            uint32_t* emissive_out, uint32_t* emissive_count_out,
+                            pt_packed_bvh_node* packed_nodes_out);
+
+/* PushConstants::PushConstants(config, scene), src/renderer/render_job.cc:836-873,
+ * with the seed passed in instead of drawn from std::random_device. */
+PT_API int pt_make_push_constants(const pt_render_config* config, const pt_camera* camera,
+                                  uint32_t emissive_triangle_count, uint32_t seed,
+                                  pt_push_constants* out);
+
+/* RenderJob::initialize_work_group_size(), src/renderer/render_job.cc:63-74 — kept only
+ * so a baseline run can state the reference's launch shape; the HIP path does not use it. */
+PT_API void pt_reference_work_group_size(uint32_t resolution_x, uint32_t resolution_y,
+                                         uint32_t* local_x, uint32_t* local_y);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* PATHTRACER_AMD_H */

@@ -1,0 +1,50 @@
+/*
+ * pt_oracle.h — CPU ORACLE (test infrastructure only; see pt_oracle.c header).
+ * Uses the public C-ABI structs of include/pathtracer_amd.h for its inputs so that a
+ * test hands byte-identical data to the oracle and to the HIP path.
+ */
+#ifndef PT_ORACLE_H
+#define PT_ORACLE_H
+
+#include "../include/pathtracer_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* build_bvh, src/bvh/bvh.cc:161-169 */
+int orc_build_bvh(const pt_vertex* vertices, uint32_t vertex_count, uint32_t* triangles,
+                  uint32_t triangle_count, uint32_t bin_count, pt_bvh_node* nodes_out,
+                  uint32_t* node_count_out, uint32_t* depth_out);
+
+/* RenderJob::process_scene, src/renderer/render_job.cc:76-121 */
+int orc_process_scene(const pt_vertex* vertices, uint32_t vertex_count, const uint32_t* triangles,
+                      uint32_t triangle_count, const pt_material* materials, uint32_t material_count,
+                      const pt_bvh_node* nodes, uint32_t node_count, float* vertex_positions_out,
+                      pt_packed_vertex* packed_vertex_out, uint32_t* emissive_out,
+                      uint32_t* emissive_count_out, pt_packed_bvh_node* packed_nodes_out);
+
+/* PushConstants ctor, src/renderer/render_job.cc:836-873 */
+int orc_make_push_constants(const pt_render_config* config, const pt_camera* camera,
+                            uint32_t emissive_triangle_count, uint32_t seed, pt_push_constants* out);
+
+/* main.comp:587-620 for the pixel rows [y_begin, y_end), num_threads host threads.
+ * Outputs are full-image buffers indexed y*resolution_x+x; rows outside the range are
+ * left untouched. Any output may be NULL. */
+int orc_render(const pt_scene_desc* scene, const pt_render_params* params, uint8_t* rgba8_out,
+               float* accum_out, uint32_t* primary_id_out, pt_stats* stats_out, int num_threads,
+               uint32_t y_begin, uint32_t y_end);
+
+/* main.comp:616-619 for one pixel's accumulator */
+void orc_resolve_pixel(float r, float g, float b, float valid, uint8_t* out_rgba);
+
+uint32_t orc_triple32(uint32_t x);
+void orc_sincos(float x, float* s, float* c);
+float orc_pow(float x, float y);
+float orc_exp2(float x);
+float orc_log2(float x);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
