@@ -1,0 +1,539 @@
+// C-ABI device entry points: context, scene upload, the wavefront render loop.
+// Replaces src/renderer/renderer.cc (device bring-up) and the Vulkan half of
+// src/renderer/render_job.cc (buffers, staging copies, dispatch, copy-back) with
+// hipMalloc / hipMemcpyAsync / kernel launches on one HIP stream.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pathtracer_amd.h"
+#include "pt_device.h"
+#include "pt_glsl_math.h"
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+
+}  // namespace
+
+struct pt_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // scene
+  bool has_scene = false;
+  pt_dev_scene scene{};
+  uint32_t emissive_count = 0;
+  std::vector<DevBuf> scene_bufs;
+  double upload_ms = 0.0;
+
+  // per-resolution working set
+  pt_dev_state state{};
+  uint32_t state_slots = 0;
+  uint32_t state_lights = 0;
+  std::vector<DevBuf> state_bufs;
+  float4* accum_out = nullptr;     // pixel order
+  uint32_t* primary_out = nullptr;
+  uint32_t* rgba8_out = nullptr;
+  uint32_t out_pixels = 0;
+
+  uint32_t* host_counts = nullptr;  // pinned
+  hipEvent_t poll_events[2] = {nullptr, nullptr};
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  std::vector<hipEvent_t> kernel_events;
+};
+
+namespace {
+
+int fail(pt_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf;
+  else g_create_error = buf;
+  return code;
+}
+
+#define PT_HIP(ctx, expr)                                                                      \
+  do {                                                                                         \
+    hipError_t e_ = (expr);                                                                    \
+    if (e_ != hipSuccess)                                                                      \
+      return fail((ctx), PT_ERR_DEVICE, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                  __FILE__, __LINE__);                                                         \
+  } while (0)
+
+void free_bufs(std::vector<DevBuf>& v) {
+  for (auto& b : v)
+    if (b.p) (void)hipFree(b.p);
+  v.clear();
+}
+
+template <class T>
+int dev_alloc(pt_ctx* ctx, std::vector<DevBuf>& owner, T** out, size_t count) {
+  void* p = nullptr;
+  size_t bytes = (count ? count : 1) * sizeof(T);
+  PT_HIP(ctx, hipMalloc(&p, bytes));
+  owner.push_back({p, bytes});
+  *out = static_cast<T*>(p);
+  return PT_OK;
+}
+
+template <class T>
+int dev_upload(pt_ctx* ctx, std::vector<DevBuf>& owner, const T** out, const T* host, size_t count) {
+  T* d = nullptr;
+  int rc = dev_alloc(ctx, owner, &d, count);
+  if (rc != PT_OK) return rc;
+  if (count) PT_HIP(ctx, hipMemcpyAsync(d, host, count * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+  *out = d;
+  return PT_OK;
+}
+
+// Host-side shape checks: every index the kernels will follow is in range before anything
+// is launched. Returns the real tree depth (root = 1) through depth_out.
+int validate_scene(pt_ctx* ctx, const pt_scene_desc* s, uint32_t* depth_out) {
+  if (!s->triangle_count || !s->vertex_positions || !s->packed_vertex_data || !s->bvh_nodes || !s->materials)
+    return fail(ctx, PT_ERR_INVALID, "scene: missing triangle / node / material arrays");
+  if (s->bvh_node_count < 1 || s->material_count < 1)
+    return fail(ctx, PT_ERR_INVALID, "scene: empty node or material array");
+  if (s->emissive_triangle_count && !s->emissive_triangles)
+    return fail(ctx, PT_ERR_INVALID, "scene: emissive list missing");
+  if ((s->directional_light_count && !s->directional_lights) || (s->point_light_count && !s->point_lights))
+    return fail(ctx, PT_ERR_INVALID, "scene: light array missing");
+
+  // tree walk: bounds of every reference + depth
+  std::vector<std::pair<uint32_t, uint32_t>> todo;  // node, depth
+  todo.emplace_back(0u, 1u);
+  uint32_t max_depth = 0;
+  size_t visited = 0;
+  while (!todo.empty()) {
+    auto [ni, depth] = todo.back();
+    todo.pop_back();
+    if (++visited > s->bvh_node_count) return fail(ctx, PT_ERR_INVALID, "scene: BVH is not a tree");
+    if (depth > max_depth) max_depth = depth;
+    const pt_packed_bvh_node& n = s->bvh_nodes[ni];
+    if (n.triangle_count > 0) {
+      if (static_cast<uint64_t>(n.left_or_begin) + n.triangle_count > s->triangle_count)
+        return fail(ctx, PT_ERR_INVALID, "scene: leaf %u references triangles out of range", ni);
+    } else {
+      if ((n.left_or_begin & 1u) || n.left_or_begin < 2 || n.left_or_begin + 1 >= s->bvh_node_count)
+        return fail(ctx, PT_ERR_INVALID, "scene: node %u has a bad child pair %u", ni, n.left_or_begin);
+      todo.emplace_back(n.left_or_begin + 1, depth + 1);
+      todo.emplace_back(n.left_or_begin, depth + 1);
+    }
+  }
+  *depth_out = max_depth;
+
+  for (uint32_t t = 0; t < s->triangle_count; ++t) {
+    int32_t mi = s->packed_vertex_data[3 * static_cast<size_t>(t)].material_index;
+    if (mi < 0 || static_cast<uint32_t>(mi) >= s->material_count)
+      return fail(ctx, PT_ERR_INVALID, "scene: triangle %u has material index %d out of range", t, mi);
+  }
+  for (uint32_t i = 0; i < s->emissive_triangle_count; ++i)
+    if (s->emissive_triangles[i] >= s->triangle_count)
+      return fail(ctx, PT_ERR_INVALID, "scene: emissive triangle index out of range");
+  auto tex_ok = [&](int32_t idx) { return idx == -1 || (idx >= 0 && static_cast<uint32_t>(idx) < s->texture_count); };
+  for (uint32_t i = 0; i < s->material_count; ++i) {
+    const pt_material& m = s->materials[i];
+    if (!tex_ok(m.base_color_texture_index) || !tex_ok(m.metallic_roughness_texture_index) ||
+        !tex_ok(m.occlusion_texture_index) || !tex_ok(m.emissive_texture_index))
+      return fail(ctx, PT_ERR_INVALID, "scene: material %u has a texture index out of range", i);
+  }
+  for (uint32_t i = 0; i < s->texture_count; ++i) {
+    const pt_texture& t = s->textures[i];
+    if (t.sampler_index < 0 || static_cast<uint32_t>(t.sampler_index) >= s->sampler_count || t.image_index < 0 ||
+        static_cast<uint32_t>(t.image_index) >= s->image_count)
+      return fail(ctx, PT_ERR_INVALID, "scene: texture %u references a sampler/image out of range", i);
+  }
+  for (uint32_t i = 0; i < s->image_count; ++i) {
+    const pt_image& im = s->images[i];
+    if (!im.width || !im.height || !im.rgba8 || im.width > 32768 || im.height > 32768)
+      return fail(ctx, PT_ERR_INVALID, "scene: image %u is empty or too large", i);
+  }
+  return PT_OK;
+}
+
+int ensure_state(pt_ctx* ctx, uint32_t slots, uint32_t lights, uint32_t pixels) {
+  if (ctx->state_slots == slots && ctx->state_lights == lights && ctx->out_pixels == pixels) return PT_OK;
+  free_bufs(ctx->state_bufs);
+  ctx->state_slots = 0;
+  pt_dev_state& st = ctx->state;
+  int rc;
+#define ALLOC(field, count) \
+  if ((rc = dev_alloc(ctx, ctx->state_bufs, &field, (count))) != PT_OK) return rc
+  ALLOC(st.ray_o, slots);
+  ALLOC(st.ray_d, slots);
+  ALLOC(st.hit, slots);
+  ALLOC(st.path_a, slots);
+  ALLOC(st.path_b, slots);
+  ALLOC(st.accum, slots);
+  ALLOC(st.primary_id, slots);
+  ALLOC(st.shadow_hdr, lights ? 4 * static_cast<size_t>(slots) : 1);
+  ALLOC(st.shadow_rec, 4 * static_cast<size_t>(slots) * lights);
+  ALLOC(st.queue[0], slots);
+  ALLOC(st.queue[1], slots);
+  ALLOC(st.shadow_queue, slots);
+  ALLOC(st.counters, PT_CNT_WORDS);
+  ALLOC(st.stats, PT_ST_WORDS);
+  ALLOC(ctx->accum_out, pixels);
+  ALLOC(ctx->primary_out, pixels);
+  ALLOC(ctx->rgba8_out, pixels);
+#undef ALLOC
+  ctx->state_slots = slots;
+  ctx->state_lights = lights;
+  ctx->out_pixels = pixels;
+  return PT_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------ C ABI
+
+extern "C" int pt_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+extern "C" int pt_device_name(int device, char* out, size_t out_size) {
+  if (!out || !out_size) return PT_ERR_INVALID;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return PT_ERR_DEVICE;
+  snprintf(out, out_size, "%s (%s, %d CUs, %.0f GiB)", prop.name, prop.gcnArchName, prop.multiProcessorCount,
+           static_cast<double>(prop.totalGlobalMem) / (1024.0 * 1024.0 * 1024.0));
+  return PT_OK;
+}
+
+extern "C" pt_ctx* pt_create(int device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n == 0) {
+    fail(nullptr, PT_ERR_DEVICE, "no HIP device available (%s)", e != hipSuccess ? hipGetErrorString(e) : "count is 0");
+    return nullptr;
+  }
+  if (device < 0) device = 0;
+  if (device >= n) {
+    fail(nullptr, PT_ERR_INVALID, "device %d out of range (%d devices)", device, n);
+    return nullptr;
+  }
+  pt_ctx* ctx = new pt_ctx();
+  ctx->device = device;
+  bool ok = hipSetDevice(device) == hipSuccess &&
+            hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
+            hipHostMalloc(reinterpret_cast<void**>(&ctx->host_counts), 64, hipHostMallocDefault) == hipSuccess &&
+            hipEventCreate(&ctx->poll_events[0]) == hipSuccess && hipEventCreate(&ctx->poll_events[1]) == hipSuccess &&
+            hipEventCreate(&ctx->ev_start) == hipSuccess && hipEventCreate(&ctx->ev_stop) == hipSuccess;
+  if (!ok) {
+    fail(nullptr, PT_ERR_DEVICE, "context set-up failed on device %d: %s", device, hipGetErrorString(hipGetLastError()));
+    pt_destroy(ctx);
+    return nullptr;
+  }
+  return ctx;
+}
+
+extern "C" void pt_destroy(pt_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  free_bufs(ctx->scene_bufs);
+  free_bufs(ctx->state_bufs);
+  if (ctx->host_counts) (void)hipHostFree(ctx->host_counts);
+  for (hipEvent_t e : ctx->poll_events)
+    if (e) (void)hipEventDestroy(e);
+  for (hipEvent_t e : ctx->kernel_events) (void)hipEventDestroy(e);
+  if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+  if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+}
+
+extern "C" const char* pt_last_error(const pt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+extern "C" int pt_upload_scene(pt_ctx* ctx, const pt_scene_desc* s) {
+  if (!ctx) return PT_ERR_INVALID;
+  if (!s) return fail(ctx, PT_ERR_INVALID, "scene is NULL");
+  PT_HIP(ctx, hipSetDevice(ctx->device));
+  uint32_t depth = 0;
+  int rc = validate_scene(ctx, s, &depth);
+  if (rc != PT_OK) return rc;
+  if (depth + 1 > 256)
+    return fail(ctx, PT_ERR_LIMIT, "BVH depth %u exceeds the LDS traversal-stack limit of 255 levels", depth);
+
+  PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  free_bufs(ctx->scene_bufs);
+  ctx->has_scene = false;
+  PT_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+
+  pt_dev_scene d{};
+  const size_t ntri = s->triangle_count;
+  static_assert(sizeof(pt_packed_bvh_node) == 32 && sizeof(pt_material) == 64, "layout");
+  if ((rc = dev_upload(ctx, ctx->scene_bufs, &d.nodes, reinterpret_cast<const float4*>(s->bvh_nodes),
+                       2 * static_cast<size_t>(s->bvh_node_count))) != PT_OK)
+    return rc;
+  if ((rc = dev_upload(ctx, ctx->scene_bufs, &d.tri_pos, reinterpret_cast<const float4*>(s->vertex_positions), 3 * ntri)) != PT_OK)
+    return rc;
+
+  // 192-byte vertex triple -> 64-byte attribute record (drops tangent, bitangent, duplicate position: Q15)
+  std::vector<float> attr(16 * ntri);
+  for (size_t t = 0; t < ntri; ++t) {
+    const pt_packed_vertex* v = s->packed_vertex_data + 3 * t;
+    float* a = attr.data() + 16 * t;
+    for (int k = 0; k < 3; ++k) std::memcpy(a + 3 * k, v[k].normal_and_texcoord_u, 12);
+    for (int k = 0; k < 3; ++k) {
+      a[9 + 2 * k] = v[k].normal_and_texcoord_u[3];
+      a[10 + 2 * k] = v[k].tangent_and_texcoord_v[3];
+    }
+    std::memcpy(a + 15, &v[0].material_index, 4);
+  }
+  if ((rc = dev_upload(ctx, ctx->scene_bufs, &d.tri_attr, reinterpret_cast<const float4*>(attr.data()), 4 * ntri)) != PT_OK)
+    return rc;
+  if ((rc = dev_upload(ctx, ctx->scene_bufs, &d.materials, reinterpret_cast<const float4*>(s->materials),
+                       4 * static_cast<size_t>(s->material_count))) != PT_OK)
+    return rc;
+  if ((rc = dev_upload(ctx, ctx->scene_bufs, &d.directional_lights, reinterpret_cast<const float4*>(s->directional_lights),
+                       2 * static_cast<size_t>(s->directional_light_count))) != PT_OK)
+    return rc;
+  if ((rc = dev_upload(ctx, ctx->scene_bufs, &d.point_lights, reinterpret_cast<const float4*>(s->point_lights),
+                       2 * static_cast<size_t>(s->point_light_count))) != PT_OK)
+    return rc;
+  if ((rc = dev_upload(ctx, ctx->scene_bufs, &d.emissive_triangles, s->emissive_triangles,
+                       static_cast<size_t>(s->emissive_triangle_count))) != PT_OK)
+    return rc;
+
+  // textures[] -> one record per combined image sampler; images -> one texel pool
+  std::vector<uint64_t> image_offset(s->image_count);
+  uint64_t total_texels = 0;
+  for (uint32_t i = 0; i < s->image_count; ++i) {
+    image_offset[i] = total_texels;
+    total_texels += static_cast<uint64_t>(s->images[i].width) * s->images[i].height;
+  }
+  if (total_texels > 0xFFFFFFFFull) return fail(ctx, PT_ERR_LIMIT, "texture pool exceeds 2^32 texels");
+  std::vector<uint32_t> pool(total_texels);
+  for (uint32_t i = 0; i < s->image_count; ++i)
+    std::memcpy(pool.data() + image_offset[i], s->images[i].rgba8, 4 * static_cast<size_t>(s->images[i].width) * s->images[i].height);
+  std::vector<uint4> trec(s->texture_count);
+  for (uint32_t i = 0; i < s->texture_count; ++i) {
+    const pt_image& im = s->images[s->textures[i].image_index];
+    const pt_sampler& sm = s->samplers[s->textures[i].sampler_index];
+    auto wrap = [](int32_t w) { return (w == PT_WRAP_CLAMP_TO_EDGE || w == PT_WRAP_MIRRORED_REPEAT) ? static_cast<uint32_t>(w) : 2u; };
+    uint32_t flags = (sm.mag_filter == PT_FILTER_NEAREST ? 0u : 1u) | (wrap(sm.wrap_s) << 2) | (wrap(sm.wrap_t) << 4);
+    trec[i] = make_uint4(static_cast<uint32_t>(image_offset[s->textures[i].image_index]), im.width, im.height, flags);
+  }
+  if ((rc = dev_upload(ctx, ctx->scene_bufs, &d.texels, pool.data(), pool.size())) != PT_OK) return rc;
+  if ((rc = dev_upload(ctx, ctx->scene_bufs, &d.textures, trec.data(), trec.size())) != PT_OK) return rc;
+
+  d.directional_light_count = s->directional_light_count;
+  d.point_light_count = s->point_light_count;
+  d.stack_entries = depth + 1;
+  d.triangle_count = s->triangle_count;
+  PT_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+  PT_HIP(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors die here
+  float ms = 0.0f;
+  PT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
+  ctx->upload_ms = ms;
+  ctx->scene = d;
+  ctx->emissive_count = s->emissive_triangle_count;
+  ctx->has_scene = true;
+  return PT_OK;
+}
+
+namespace {
+
+hipEvent_t next_kernel_event(pt_ctx* ctx, size_t& used) {
+  if (used == ctx->kernel_events.size()) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    ctx->kernel_events.push_back(e);
+  }
+  return ctx->kernel_events[used++];
+}
+
+int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint32_t* primary_dev, hipStream_t stream,
+                 pt_stats* stats_out) {
+  if (!ctx->has_scene) return fail(ctx, PT_ERR_NO_SCENE, "pt_upload_scene has not been called");
+  const pt_push_constants& pc = p->pc;
+  if (!pc.resolution_x || !pc.resolution_y || pc.resolution_x > 65536 || pc.resolution_y > 65536)
+    return fail(ctx, PT_ERR_INVALID, "resolution %ux%u out of range", pc.resolution_x, pc.resolution_y);
+  if (pc.emissive_triangle_count != ctx->emissive_count)
+    return fail(ctx, PT_ERR_INVALID, "push constants say %u emissive triangles, the uploaded scene has %u",
+                pc.emissive_triangle_count, ctx->emissive_count);
+  const uint32_t num_ranks = p->num_ranks ? p->num_ranks : 1;
+  if (p->rank >= num_ranks) return fail(ctx, PT_ERR_INVALID, "rank %u >= num_ranks %u", p->rank, num_ranks);
+
+  pt_dev_frame f{};
+  f.pc = pc;
+  for (int k = 0; k < 3; ++k) f.bg_linear[k] = pt_pow(pc.bg_color[k], 2.2f);
+  f.sqrt_samples = static_cast<uint32_t>(static_cast<int32_t>(std::sqrt(static_cast<float>(pc.sample_count))));
+  const uint32_t total = f.sqrt_samples * f.sqrt_samples;
+  if (f.sqrt_samples == 0 || total >= (1u << 24))
+    return fail(ctx, PT_ERR_LIMIT, "sample_count %u gives %u strata; supported range is 1 .. 2^24-1", pc.sample_count, total);
+  f.rank = p->rank;
+  f.num_ranks = num_ranks;
+  f.sample_begin = static_cast<uint32_t>((static_cast<uint64_t>(p->rank) * total) / num_ranks);
+  f.sample_end = static_cast<uint32_t>((static_cast<uint64_t>(p->rank + 1) * total) / num_ranks);
+  f.tiles_x = (pc.resolution_x + 7) / 8;
+  const uint32_t tiles_y = (pc.resolution_y + 7) / 8;
+  const uint64_t slots64 = static_cast<uint64_t>(f.tiles_x) * tiles_y * 64;
+  if (slots64 > 0x7FFFFFFFull) return fail(ctx, PT_ERR_LIMIT, "image too large");
+  f.slot_count = static_cast<uint32_t>(slots64);
+  const uint32_t pixels = pc.resolution_x * pc.resolution_y;
+
+  const pt_dev_scene& sc = ctx->scene;
+  const uint32_t n_lights = sc.directional_light_count + sc.point_light_count + (pc.emissive_triangle_count ? 1u : 0u);
+  int rc = ensure_state(ctx, f.slot_count, n_lights, pixels);
+  if (rc != PT_OK) return rc;
+  const pt_dev_state& st = ctx->state;
+  if (!accum_dev) accum_dev = ctx->accum_out;
+
+  // traversal block size: the LDS stack is block * stack_entries words, kept within 64 KiB
+  const uint32_t trace_block = (256u * sc.stack_entries * 4u <= 65536u) ? 256u : 64u;
+  const bool time_kernels = (p->flags & PT_FLAG_TIME_KERNELS) != 0;
+  size_t ev_used = 0;
+  std::vector<std::pair<size_t, int>> ev_kind;  // index of the start event, 0 = trace, 1 = shade
+
+  PT_HIP(ctx, hipMemsetAsync(st.counters, 0, PT_CNT_WORDS * sizeof(uint32_t), stream));
+  PT_HIP(ctx, hipMemsetAsync(st.stats, 0, PT_ST_WORDS * sizeof(unsigned long long), stream));
+  PT_HIP(ctx, hipEventRecord(ctx->ev_start, stream));
+  ptd::launch_init(f, st, stream);
+
+  auto timed = [&](int kind, auto&& launch) {
+    if (time_kernels) {
+      hipEvent_t a = next_kernel_event(ctx, ev_used);
+      hipEvent_t b = next_kernel_event(ctx, ev_used);
+      if (a && b) {
+        ev_kind.emplace_back(ev_used - 2, kind);
+        (void)hipEventRecord(a, stream);
+        launch();
+        (void)hipEventRecord(b, stream);
+        return;
+      }
+    }
+    launch();
+  };
+
+  // One path needs at most 8 light steps + 4 pass-through vertices (main.comp:18-19, 512, 542).
+  const uint64_t max_iters = static_cast<uint64_t>(f.sample_end - f.sample_begin) * 12ull + 2ull;
+  constexpr uint32_t kBatch = 16;
+  uint32_t bound = pixels;  // live entries never increase: the last polled count bounds every later queue
+  uint64_t iter = 0;
+  int poll = 0;
+  bool have_prev = false;
+  bool drained = (f.sample_begin == f.sample_end);
+  while (!drained && iter < max_iters) {
+    for (uint32_t b = 0; b < kBatch; ++b, ++iter) {
+      const uint32_t parity = static_cast<uint32_t>(iter & 1u);
+      timed(0, [&] { ptd::launch_extend(sc, st, parity, bound, trace_block, stream); });
+      timed(1, [&] { ptd::launch_shade(sc, f, st, parity, bound, stream); });
+      if (n_lights) timed(0, [&] { ptd::launch_shadow(sc, f, st, bound, trace_block, stream); });
+    }
+    PT_HIP(ctx, hipGetLastError());
+    // entries queued for the NEXT iteration; stays intact until that iteration's successor recycles it
+    PT_HIP(ctx, hipMemcpyAsync(&ctx->host_counts[poll], st.counters + PT_CNT_QUEUE0 + (iter & 1u), sizeof(uint32_t),
+                               hipMemcpyDeviceToHost, stream));
+    PT_HIP(ctx, hipEventRecord(ctx->poll_events[poll], stream));
+    if (have_prev) {  // look at the previous batch while this one runs: the GPU never waits for the host
+      PT_HIP(ctx, hipEventSynchronize(ctx->poll_events[poll ^ 1]));
+      const uint32_t live = ctx->host_counts[poll ^ 1];
+      if (live == 0) drained = true;
+      else if (live < bound) bound = live;
+    }
+    have_prev = true;
+    poll ^= 1;
+  }
+  if (!drained) {
+    PT_HIP(ctx, hipEventSynchronize(ctx->poll_events[poll ^ 1]));
+    if (ctx->host_counts[poll ^ 1] != 0)
+      return fail(ctx, PT_ERR_DEVICE, "wavefront loop did not drain after %llu iterations", static_cast<unsigned long long>(iter));
+  }
+  ptd::launch_finalize(f, st, accum_dev, primary_dev ? primary_dev : ctx->primary_out, stream);
+  PT_HIP(ctx, hipEventRecord(ctx->ev_stop, stream));
+  PT_HIP(ctx, hipGetLastError());
+  PT_HIP(ctx, hipStreamSynchronize(stream));
+
+  if (stats_out) {
+    unsigned long long h[PT_ST_WORDS];
+    PT_HIP(ctx, hipMemcpy(h, st.stats, sizeof(h), hipMemcpyDeviceToHost));
+    std::memset(stats_out, 0, sizeof(*stats_out));
+    stats_out->paths = h[PT_ST_PATHS];
+    stats_out->rays = h[PT_ST_RAYS];
+    stats_out->node_visits = h[PT_ST_VISITS];
+    stats_out->tri_tests = h[PT_ST_TESTS];
+    stats_out->hits_shaded = h[PT_ST_HITS];
+    stats_out->texture_taps = h[PT_ST_TAPS];
+    stats_out->shaded_vertices = h[PT_ST_VERTS];
+    stats_out->nan_samples = h[PT_ST_NANS];
+    stats_out->iterations = iter;
+    float ms = 0.0f;
+    PT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
+    stats_out->render_ms = ms;
+    stats_out->upload_ms = ctx->upload_ms;
+    for (auto& [idx, kind] : ev_kind) {
+      float k = 0.0f;
+      if (hipEventElapsedTime(&k, ctx->kernel_events[idx], ctx->kernel_events[idx + 1]) == hipSuccess)
+        (kind == 0 ? stats_out->trace_ms : stats_out->shade_ms) += k;
+    }
+  }
+  return PT_OK;
+}
+
+}  // namespace
+
+extern "C" int pt_render_accum_device(pt_ctx* ctx, const pt_render_params* params, float* accum_dev,
+                                      uint32_t* primary_id_dev, void* stream, pt_stats* stats_out) {
+  if (!ctx) return PT_ERR_INVALID;
+  if (!params || !accum_dev) return fail(ctx, PT_ERR_INVALID, "params / accum_dev is NULL");
+  PT_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+  return render_accum(ctx, params, reinterpret_cast<float4*>(accum_dev), primary_id_dev, s, stats_out);
+}
+
+extern "C" int pt_resolve_device(pt_ctx* ctx, const float* accum_dev, uint32_t pixel_count, uint8_t* rgba8_dev,
+                                 void* stream) {
+  if (!ctx) return PT_ERR_INVALID;
+  if (!accum_dev || !rgba8_dev || !pixel_count) return fail(ctx, PT_ERR_INVALID, "resolve: NULL buffer or no pixels");
+  PT_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+  ptd::launch_resolve(reinterpret_cast<const float4*>(accum_dev), pixel_count, reinterpret_cast<uint32_t*>(rgba8_dev), s);
+  PT_HIP(ctx, hipGetLastError());
+  return PT_OK;
+}
+
+extern "C" int pt_render(pt_ctx* ctx, const pt_render_params* params, uint8_t* rgba8_out, float* accum_out,
+                         uint32_t* primary_id_out, pt_stats* stats_out) {
+  if (!ctx) return PT_ERR_INVALID;
+  if (!params) return fail(ctx, PT_ERR_INVALID, "params is NULL");
+  PT_HIP(ctx, hipSetDevice(ctx->device));
+  int rc = render_accum(ctx, params, nullptr, nullptr, ctx->stream, stats_out);
+  if (rc != PT_OK) return rc;
+  const uint32_t pixels = params->pc.resolution_x * params->pc.resolution_y;
+  PT_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+  if (rgba8_out) {
+    ptd::launch_resolve(ctx->accum_out, pixels, ctx->rgba8_out, ctx->stream);
+    PT_HIP(ctx, hipGetLastError());
+    PT_HIP(ctx, hipMemcpyAsync(rgba8_out, ctx->rgba8_out, 4 * static_cast<size_t>(pixels), hipMemcpyDeviceToHost, ctx->stream));
+  }
+  if (accum_out)
+    PT_HIP(ctx, hipMemcpyAsync(accum_out, ctx->accum_out, 16 * static_cast<size_t>(pixels), hipMemcpyDeviceToHost, ctx->stream));
+  if (primary_id_out)
+    PT_HIP(ctx, hipMemcpyAsync(primary_id_out, ctx->primary_out, 4 * static_cast<size_t>(pixels), hipMemcpyDeviceToHost, ctx->stream));
+  PT_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+  PT_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (stats_out) {
+    float ms = 0.0f;
+    PT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
+    stats_out->download_ms = ms;
+  }
+  return PT_OK;
+}

@@ -1,0 +1,77 @@
+// Device-side data layout shared by the kernels (pt_kernels.hip) and the context that
+// owns the HBM allocations (pt_context.hip).  See DESIGN.md "Data layout in HBM".
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pathtracer_amd.h"
+
+// counters[] words
+enum { PT_CNT_QUEUE0 = 0, PT_CNT_QUEUE1 = 1, PT_CNT_SHADOW = 2, PT_CNT_WORDS = 4 };
+// stats[] words (unsigned long long), order of flush_tally()
+enum { PT_ST_PATHS = 0, PT_ST_RAYS, PT_ST_VISITS, PT_ST_TESTS, PT_ST_HITS, PT_ST_TAPS, PT_ST_VERTS, PT_ST_NANS, PT_ST_WORDS };
+
+// The scene in HBM, split by who reads it:
+//   nodes      traversal only   — the reference's 32-byte PackedBVHNode array verbatim; a
+//                                  sibling pair {2k,2k+1} is one aligned 64-byte record
+//   tri_pos    traversal + shade — the reference's binding 0 verbatim: 3 x vec4 per triangle
+//   tri_attr   shade only        — 64 bytes per triangle: 3 normals, 3 uvs, material index
+//                                  (the reference's 192-byte vertex triple minus the
+//                                  tangent / bitangent / duplicate position it never reads, Q15)
+//   materials  shade             — the reference's 64-byte Material array verbatim
+struct pt_dev_scene {
+  const float4* nodes;
+  const float4* tri_pos;
+  const float4* tri_attr;
+  const float4* materials;
+  const float4* directional_lights;  // 2 x float4 per light
+  const float4* point_lights;
+  const uint32_t* emissive_triangles;
+  const uint4* textures;             // {texel offset, width, height, mag_filter | wrap_s << 2 | wrap_t << 4}
+  const uint32_t* texels;            // all images, RGBA8 packed little-endian
+  uint32_t directional_light_count;
+  uint32_t point_light_count;
+  uint32_t stack_entries;            // LDS stack rows per lane (bvh_max_depth + 1)
+  uint32_t triangle_count;
+};
+
+struct pt_dev_frame {
+  pt_push_constants pc;
+  float bg_linear[3];      // pow(bg_color_srgb, GAMMA), main.comp:506
+  uint32_t sqrt_samples;   // int(sqrt(sample_count)), main.comp:596
+  uint32_t sample_begin;   // strata [begin, end) rendered by this rank
+  uint32_t sample_end;
+  uint32_t rank, num_ranks;
+  uint32_t slot_count;     // tiles_x * tiles_y * 64
+  uint32_t tiles_x;
+};
+
+// Per-slot path state, SoA of 16-byte words (one coalesced dwordx4 access per field per wave)
+struct pt_dev_state {
+  float4* ray_o;       // origin.xyz
+  float4* ray_d;       // direction.xyz
+  uint4* hit;          // triangle, u, v, t
+  float4* path_a;      // throughput (`indirect`).xyz, rng state
+  float4* path_b;      // radiance (`color`).xyz, packed step counters + stratum
+  float4* accum;       // sum of valid samples .xyz, dropped-sample count
+  uint32_t* primary_id;
+  float4* shadow_hdr;  // 4 per slot: {emission, weight} {indirect before, last-vertex flag} {indirect after} {origin}
+  float4* shadow_rec;  // 4 per light per slot: {l, distance} {radiance, correction} {brdf, n.l} {pdf}
+  uint32_t* queue[2];
+  uint32_t* shadow_queue;
+  uint32_t* counters;
+  unsigned long long* stats;
+};
+
+namespace ptd {
+void launch_init(const pt_dev_frame& f, const pt_dev_state& st, hipStream_t s);
+void launch_extend(const pt_dev_scene& sc, const pt_dev_state& st, uint32_t parity, uint32_t max_entries, uint32_t block,
+                   hipStream_t s);
+void launch_shade(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity,
+                  uint32_t max_entries, hipStream_t s);
+void launch_shadow(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t max_entries,
+                   uint32_t block, hipStream_t s);
+void launch_finalize(const pt_dev_frame& f, const pt_dev_state& st, float4* accum_out, uint32_t* primary_out, hipStream_t s);
+void launch_resolve(const float4* accum, uint32_t pixel_count, uint32_t* rgba8, hipStream_t s);
+}  // namespace ptd

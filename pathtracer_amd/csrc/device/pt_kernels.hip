@@ -1,0 +1,845 @@
+// Wavefront path-tracing kernels for gfx950 (wave64): the device half of the hot path,
+// i.e. the work of src/renderer/shaders/main.comp re-organised from "one invocation owns
+// a pixel for all its samples" into queues of path segments:
+//
+//   k_init     main():588-605 for the first sample of every pixel slot
+//   k_extend   ray_scene_intersect (main.comp:263-304) for every queued ray
+//   k_shade    trace() body (main.comp:517-577) for every extended ray: miss handling,
+//              interpolation, material, light sampling set-up, BSDF sampling, path
+//              regeneration (main():597-612) and queue compaction
+//   k_shadow   ray_scene_intersect_with_transparency (main.comp:306-332) for the vertex's
+//              light samples and the direct-lighting accumulate (main.comp:536-552)
+//   k_finalize slot order -> pixel order, float4 accumulator + primary-hit ids
+//   k_resolve  main():616-619
+//
+// A pixel owns ONE RNG stream consumed sequentially across all its samples,
+// so a pixel slot carries one path at a time and regenerates the next sample as soon as
+// the current one ends; the queues hold slot indices and are re-compacted every
+// iteration with ballot + mbcnt (one atomic per wave).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pt_device.h"
+#include "pt_vec.h"
+
+using namespace ptd;
+
+namespace {
+
+constexpr float kPi = 3.1415926535f;         // main.comp:13
+constexpr float kGamma = 2.2f;               // :14
+constexpr float kInfinity = 3.4e+38f;        // :15
+constexpr float kNormalDelta = 1e-4f;        // :16
+constexpr float kPointLightRadius = 0.2f;    // :17
+constexpr uint32_t kMaxTransparencySteps = 4;  // :18
+constexpr uint32_t kMaxLightSteps = 8;       // :19
+constexpr float kClamp = 10.0f;              // :20
+constexpr float kEpsilon = 1e-6f;            // :21
+constexpr uint32_t kNoHit = 0xFFFFFFFFu;
+// glslang folds these constant expressions in double precision before rounding to float
+constexpr float kLightArea = static_cast<float>(4.0 * 3.1415926535 * 0.2 * 0.2);  // :450
+constexpr float kFourPi = static_cast<float>(4.0 * 3.1415926535);                 // :451
+constexpr float kInvGamma = static_cast<float>(1.0 / 2.2);                        // :617
+
+// ---- per-slot counters word: light steps [0,4) | transparency steps [4,7) | primary flag 7 | sample [8,32)
+__device__ __forceinline__ uint32_t ctr_light(uint32_t c) { return c & 15u; }
+__device__ __forceinline__ uint32_t ctr_transp(uint32_t c) { return (c >> 4) & 7u; }
+__device__ __forceinline__ bool ctr_primary(uint32_t c) { return (c >> 7) & 1u; }
+__device__ __forceinline__ uint32_t ctr_sample(uint32_t c) { return c >> 8; }
+__device__ __forceinline__ uint32_t ctr_pack(uint32_t light, uint32_t transp, bool primary, uint32_t sample) {
+  return light | (transp << 4) | (primary ? 128u : 0u) | (sample << 8);
+}
+
+// ---------------------------------------------------------------- RNG (main.comp:135-149)
+__device__ __forceinline__ uint32_t triple32(uint32_t x) {
+  x ^= x >> 17; x *= 0xed5ad4bbu;
+  x ^= x >> 11; x *= 0xac4c1b51u;
+  x ^= x >> 15; x *= 0x31848babu;
+  x ^= x >> 14;
+  return x;
+}
+__device__ __forceinline__ float rand_float(uint32_t& state) {
+  state = triple32(state);
+  return static_cast<float>(state) / 4294967296.0f;  // float(~0u) == 2^32 (Q3)
+}
+
+// ---------------------------------------------------------------- wave primitives
+__device__ __forceinline__ uint32_t lane_id() {
+  return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+// Compacting append: every lane of the wave must call it (converged). Returns the slot in
+// the destination queue for lanes with `pred`, one atomic per wave.
+__device__ __forceinline__ uint32_t wave_append(bool pred, uint32_t* counter) {
+  const uint64_t mask = __ballot(pred);
+  const uint32_t before =
+      __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+  uint32_t base = 0;
+  if (lane_id() == 0 && mask != 0) base = atomicAdd(counter, static_cast<uint32_t>(__popcll(mask)));
+  base = __builtin_amdgcn_readfirstlane(base);
+  return base + before;
+}
+
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;
+}
+
+struct Tally {  // per-thread work counters, flushed once per kernel
+  uint32_t rays = 0, visits = 0, tests = 0, hits = 0, taps = 0, verts = 0, paths = 0, nans = 0;
+};
+
+__device__ __forceinline__ void flush_tally(const Tally& t, unsigned long long* stats) {
+  uint32_t v[8] = {t.paths, t.rays, t.visits, t.tests, t.hits, t.taps, t.verts, t.nans};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    uint32_t s = wave_sum(v[i]);
+    if (lane_id() == 0 && s) atomicAdd(&stats[i], static_cast<unsigned long long>(s));
+  }
+}
+
+// ---------------------------------------------------------------- traversal
+struct Hit {
+  float t, u, v;
+  uint32_t tri;
+};
+
+// ray_triangle_intersect, main.comp:189-217. Positions are the reference's binding 0:
+// three vec4 per triangle (48 B, one aligned 16-B load per vertex).
+__device__ __forceinline__ void ray_triangle(const float4* __restrict__ tri_pos, vec3 o, vec3 d, uint32_t tri, Hit& h) {
+  const float4 q0 = tri_pos[3 * static_cast<size_t>(tri)];
+  const float4 q1 = tri_pos[3 * static_cast<size_t>(tri) + 1];
+  const float4 q2 = tri_pos[3 * static_cast<size_t>(tri) + 2];
+  const vec3 p0 = xyz(q0);
+  const vec3 edge1 = xyz(q1) - p0;
+  const vec3 edge2 = xyz(q2) - p0;
+  const vec3 ray_cross_edge2 = cross(d, edge2);
+  const float det = dot(edge1, ray_cross_edge2);
+  if (__builtin_fabsf(det) < kEpsilon) return;
+
+  const float inv_det = 1.0f / det;
+  const vec3 s = o - p0;
+  const float u = inv_det * dot(s, ray_cross_edge2);
+  if (u < 0.0f || u > 1.0f) return;
+
+  const vec3 s_cross_edge1 = cross(s, edge1);
+  const float v = inv_det * dot(d, s_cross_edge1);
+  if (v < 0.0f || u + v > 1.0f) return;
+
+  const float t = inv_det * dot(edge2, s_cross_edge1);
+  if (t > kEpsilon && t < h.t) {
+    h.t = t;
+    h.u = u;
+    h.v = v;
+    h.tri = tri;
+  }
+}
+
+// ray_aabb_intersect, main.comp:169-185, with inv_dir hoisted out of the loop (bit-identical)
+__device__ __forceinline__ bool ray_box(vec3 o, vec3 inv, const float4& bmin, const float4& bmax, float& t_near) {
+  const vec3 t_min = inv * (xyz(bmin) - o);
+  const vec3 t_max = inv * (xyz(bmax) - o);
+  const float n = gmax(gmax(gmin(t_min.x, t_max.x), gmin(t_min.y, t_max.y)), gmin(t_min.z, t_max.z));
+  const float f = gmin(gmin(gmax(t_min.x, t_max.x), gmax(t_min.y, t_max.y)), gmax(t_min.z, t_max.z));
+  t_near = n;
+  return n <= f;
+}
+
+// ray_scene_intersect, main.comp:263-304. Same visiting order as the reference (near child
+// first, far child deferred, leaf triangles in index order, no re-cull on pop): when both
+// children are hit the near one is entered directly instead of being pushed and popped.
+// The deferred far children live in an LDS stack, one column per lane
+// (stack[level * stride + lane]: conflict-free ds_read/ds_write_b32).
+// A sibling pair {2k, 2k+1} is one aligned 64-byte record (4 x float4).
+__device__ __forceinline__ void closest_hit(const float4* __restrict__ nodes, const float4* __restrict__ tri_pos,
+                                            vec3 o, vec3 d, Hit& h, uint32_t* stack, uint32_t stride, Tally& tally) {
+  ++tally.rays;
+  const vec3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  uint32_t sp = 0;
+  uint32_t lob = fbits(nodes[0].w);  // root: never box-tested (Q13)
+  uint32_t cnt = fbits(nodes[1].w);
+  for (;;) {
+    if (cnt > 0) {
+      tally.tests += cnt;
+      for (uint32_t i = 0; i < cnt; ++i) ray_triangle(tri_pos, o, d, lob + i, h);
+    } else {
+      ++tally.visits;
+      const float4* pair = nodes + 2 * static_cast<size_t>(lob);
+      const float4 l0 = pair[0], l1 = pair[1], r0 = pair[2], r1 = pair[3];
+      float dist_l, dist_r;
+      bool hit_l = ray_box(o, inv, l0, l1, dist_l);
+      bool hit_r = ray_box(o, inv, r0, r1, dist_r);
+      hit_l = hit_l && (dist_l < h.t);
+      hit_r = hit_r && (dist_r < h.t);
+      if (hit_l || hit_r) {
+        const bool go_left = hit_l && (!hit_r || dist_l < dist_r);  // equal distances: right is near (Q14)
+        if (hit_l && hit_r) {
+          stack[sp * stride] = go_left ? lob + 1 : lob;
+          ++sp;
+        }
+        const uint32_t nl = go_left ? fbits(l0.w) : fbits(r0.w);
+        cnt = go_left ? fbits(l1.w) : fbits(r1.w);
+        lob = nl;
+        continue;
+      }
+    }
+    if (sp == 0) break;
+    --sp;
+    const uint32_t idx = stack[sp * stride];
+    lob = fbits(nodes[2 * static_cast<size_t>(idx)].w);
+    cnt = fbits(nodes[2 * static_cast<size_t>(idx) + 1].w);
+  }
+}
+
+// ---------------------------------------------------------------- scene fetch
+struct TriAttr {  // 64-byte attribute record: normals, uvs, material of one triangle
+  vec3 n0, n1, n2;
+  float u0, v0, u1, v1, u2, v2;
+  uint32_t mat;
+};
+
+__device__ __forceinline__ TriAttr load_attr(const float4* __restrict__ tri_attr, uint32_t tri) {
+  const float4* p = tri_attr + 4 * static_cast<size_t>(tri);
+  const float4 a = p[0], b = p[1], c = p[2], e = p[3];
+  TriAttr r;
+  r.n0 = mk(a.x, a.y, a.z);
+  r.n1 = mk(a.w, b.x, b.y);
+  r.n2 = mk(b.z, b.w, c.x);
+  r.u0 = c.y; r.v0 = c.z; r.u1 = c.w;
+  r.v1 = e.x; r.u2 = e.y; r.v2 = e.z;
+  r.mat = fbits(e.w);
+  return r;
+}
+
+struct Material {  // main.comp:42-58
+  float4 base_color;
+  int base_tex;
+  float metallic, roughness;
+  int mr_tex;
+  float occlusion_strength;
+  int occlusion_tex;
+  vec3 emissive;
+  int emissive_tex;
+};
+
+__device__ __forceinline__ Material load_material(const float4* __restrict__ mats, uint32_t idx) {
+  const float4* p = mats + 4 * static_cast<size_t>(idx);
+  const float4 a = p[0], b = p[1], c = p[2], e = p[3];
+  Material m;
+  m.base_color = a;
+  m.base_tex = static_cast<int>(fbits(b.x));
+  m.metallic = b.y;
+  m.roughness = b.z;
+  m.mr_tex = static_cast<int>(fbits(b.w));
+  m.occlusion_strength = c.z;
+  m.occlusion_tex = static_cast<int>(fbits(c.w));
+  m.emissive = mk(e.x, e.y, e.z);
+  m.emissive_tex = static_cast<int>(fbits(e.w));
+  return m;
+}
+
+// texture(): R8G8B8A8_UNORM, single mip, LOD 0 -> magnification filter; unnormalised
+// coordinate s*W - 0.5 (linear) or floor(s*W) (nearest); wrap on integer texel coordinates
+// (render_job.cc:246-252, 268-292, 889-915). Same definition as the CPU oracle.
+__device__ __forceinline__ int wrap_coord(int i, int n, uint32_t mode) {
+  if (mode == 2u) {  // repeat
+    int m = i % n;
+    return m < 0 ? m + n : m;
+  }
+  if (mode == 1u) {  // mirrored repeat
+    const int period = 2 * n;
+    int m = i % period;
+    if (m < 0) m += period;
+    return m < n ? m : period - 1 - m;
+  }
+  return i < 0 ? 0 : (i > n - 1 ? n - 1 : i);  // clamp to edge
+}
+
+__device__ __forceinline__ float4 texel(const uint32_t* __restrict__ texels, uint32_t base, int w, int x, int y) {
+  const uint32_t p = texels[base + static_cast<uint32_t>(y) * static_cast<uint32_t>(w) + static_cast<uint32_t>(x)];
+  return make_float4(static_cast<float>(p & 255u) / 255.0f, static_cast<float>((p >> 8) & 255u) / 255.0f,
+                     static_cast<float>((p >> 16) & 255u) / 255.0f, static_cast<float>(p >> 24) / 255.0f);
+}
+
+// sample_texture, main.comp:221-224
+__device__ __forceinline__ float4 sample_texture(const pt_dev_scene& sc, int index, float s, float t, Tally& tally) {
+  if (index == -1) return make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+  ++tally.taps;
+  const uint4 rec = sc.textures[index];  // texel offset, width, height, mag | wrap_s << 2 | wrap_t << 4
+  const int W = static_cast<int>(rec.y), H = static_cast<int>(rec.z);
+  const uint32_t wrap_s = (rec.w >> 2) & 3u, wrap_t = (rec.w >> 4) & 3u;
+  if ((rec.w & 3u) == 0u) {  // nearest
+    const int i = static_cast<int>(__builtin_floorf(s * static_cast<float>(W)));
+    const int j = static_cast<int>(__builtin_floorf(t * static_cast<float>(H)));
+    return texel(sc.texels, rec.x, W, wrap_coord(i, W, wrap_s), wrap_coord(j, H, wrap_t));
+  }
+  const float u = s * static_cast<float>(W) - 0.5f, v = t * static_cast<float>(H) - 0.5f;
+  const float fu = __builtin_floorf(u), fv = __builtin_floorf(v);
+  const float a = u - fu, b = v - fv;
+  const int i0 = static_cast<int>(fu), j0 = static_cast<int>(fv);
+  const int x0 = wrap_coord(i0, W, wrap_s), x1 = wrap_coord(i0 + 1, W, wrap_s);
+  const int y0 = wrap_coord(j0, H, wrap_t), y1 = wrap_coord(j0 + 1, H, wrap_t);
+  const float4 t00 = texel(sc.texels, rec.x, W, x0, y0), t10 = texel(sc.texels, rec.x, W, x1, y0);
+  const float4 t01 = texel(sc.texels, rec.x, W, x0, y1), t11 = texel(sc.texels, rec.x, W, x1, y1);
+  const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+  float4 r;
+  r.x = ((w00 * t00.x + w10 * t10.x) + w01 * t01.x) + w11 * t11.x;
+  r.y = ((w00 * t00.y + w10 * t10.y) + w01 * t01.y) + w11 * t11.y;
+  r.z = ((w00 * t00.z + w10 * t10.z) + w01 * t01.z) + w11 * t11.z;
+  r.w = ((w00 * t00.w + w10 * t10.w) + w01 * t01.w) + w11 * t11.w;
+  return r;
+}
+
+// sRGB decode of a sampled colour; an untextured lookup is vec4(1) and pow(1, 2.2) == 1 exactly
+__device__ __forceinline__ vec3 decode_srgb(int tex_index, const float4& s) {
+  if (tex_index == -1) return splat(1.0f);
+  return pow3(mk(s.x, s.y, s.z), kGamma);
+}
+
+// get_interpolated_data without the normal (the shadow walk never reads it), main.comp:226-240
+__device__ __forceinline__ void interpolate_pos_uv(const pt_dev_scene& sc, uint32_t tri, vec3 wuv, vec3& pos,
+                                                   float& tu, float& tv, uint32_t& mat, vec3* normal, Tally& tally) {
+  ++tally.hits;
+  const float4 q0 = sc.tri_pos[3 * static_cast<size_t>(tri)];
+  const float4 q1 = sc.tri_pos[3 * static_cast<size_t>(tri) + 1];
+  const float4 q2 = sc.tri_pos[3 * static_cast<size_t>(tri) + 2];
+  const TriAttr at = load_attr(sc.tri_attr, tri);
+  pos = mat3_mul(xyz(q0), xyz(q1), xyz(q2), wuv);
+  if (normal) *normal = normalize(mat3_mul(at.n0, at.n1, at.n2, wuv));
+  tu = at.u0 * wuv.x + at.u1 * wuv.y + at.u2 * wuv.z;
+  tv = at.v0 * wuv.x + at.v1 * wuv.y + at.v2 * wuv.z;
+  mat = at.mat;
+}
+
+// ---------------------------------------------------------------- BRDF (main.comp:336-366)
+__device__ __forceinline__ float distribution_ggx(float n_dot_h, float a2) {
+  if (a2 < kEpsilon && n_dot_h > 1.0f - kEpsilon) return 1.0f;
+  float denom = n_dot_h * n_dot_h * (a2 - 1.0f) + 1.0f;
+  denom = kPi * denom * denom;
+  return a2 / denom;
+}
+
+__device__ __forceinline__ float geometry_smith1(vec3 n, vec3 h, vec3 x, float a2) {
+  if (dot(h, x) <= 0.0f) return 0.0f;
+  const float n_dot_x = dot(n, x);
+  const float denom = __builtin_fabsf(n_dot_x) + __fsqrt_rn(a2 + (1.0f - a2) * n_dot_x * n_dot_x);
+  return 1.0f / denom;
+}
+
+__device__ __forceinline__ vec3 microfacet_brdf(vec3 n, vec3 v, vec3 l, float metal, float a2, vec3 base_color) {
+  const vec3 h = normalize(l + v);
+  const float n_dot_h = gmax(dot(n, h), kEpsilon);
+  const vec3 f0 = splat(0.04f) * (1.0f - metal) + base_color * metal;  // mix()
+  const vec3 f = f0 + (splat(1.0f) - f0) * pt_pow(1.0f - __builtin_fabsf(dot(v, h)), 5.0f);
+  const vec3 diffuse = (splat(1.0f) - f) * (1.0f - metal) * base_color / kPi;
+  // geometry_smith2(n, h, l, v, a2) at the call site: G1(l) * G1(v) with the roles as written (:353, :364)
+  const float g2 = geometry_smith1(n, h, v, a2) * geometry_smith1(n, h, l, a2);
+  const vec3 specular = f * distribution_ggx(n_dot_h, a2) * g2;
+  return diffuse + specular;
+}
+
+// ---------------------------------------------------------------- sampling (main.comp:151-165, 370-405)
+struct Basis {
+  vec3 u, v, w;
+};
+__device__ __forceinline__ Basis orthogonal_matrix(vec3 w) {
+  const vec3 a = (__builtin_fabsf(w.x) > 0.9f) ? mk(0.0f, 1.0f, 0.0f) : mk(1.0f, 0.0f, 0.0f);
+  Basis b;
+  b.v = normalize(cross(w, a));
+  b.u = cross(w, b.v);
+  b.w = w;
+  return b;
+}
+__device__ __forceinline__ vec3 to_world(const Basis& b, vec3 p) { return mat3_mul(b.u, b.v, b.w, p); }
+
+__device__ __forceinline__ vec3 uniform_hemisphere_sampling(vec3 n, uint32_t& rng) {
+  const float phi = 2.0f * kPi * rand_float(rng);
+  const float cos_theta = 1.0f - rand_float(rng);
+  const float sin_theta = __fsqrt_rn(1.0f - cos_theta * cos_theta);
+  float sp, cp;
+  pt_sincos(phi, &sp, &cp);
+  return to_world(orthogonal_matrix(n), mk(cp * sin_theta, sp * sin_theta, cos_theta));
+}
+
+__device__ __forceinline__ vec3 diffuse_sample(vec3 n, uint32_t& rng, float& pdf) {
+  const float phi = 2.0f * kPi * rand_float(rng);
+  const float rnd = rand_float(rng);
+  float sp, cp;
+  pt_sincos(phi, &sp, &cp);
+  const float sr = __fsqrt_rn(rnd);
+  const vec3 l = to_world(orthogonal_matrix(n), mk(cp * sr, sp * sr, __fsqrt_rn(1.0f - rnd)));
+  pdf = gmax(dot(n, l), 0.0f) / kPi;
+  return l;
+}
+
+__device__ __forceinline__ vec3 microfacet_sample(vec3 n, vec3 v, float a2, uint32_t& rng, float& pdf) {
+  const float phi = 2.0f * kPi * rand_float(rng);
+  const float rnd = rand_float(rng);
+  const float cos2_theta = gmin(gmax((1.0f - rnd) / (rnd * (a2 - 1.0f) + 1.0f), 0.0f), 1.0f);
+  const float cos_theta = __fsqrt_rn(cos2_theta);
+  const float sin_theta = __fsqrt_rn(1.0f - cos2_theta);
+  float sp, cp;
+  pt_sincos(phi, &sp, &cp);
+  const vec3 h = normalize(to_world(orthogonal_matrix(n), mk(cp * sin_theta, sp * sin_theta, cos_theta)));
+  const vec3 i = -v;
+  const vec3 l = i - h * (2.0f * dot(h, i));  // reflect(-v, h)
+  pdf = distribution_ggx(cos_theta, a2) * cos_theta / (4.0f * __builtin_fabsf(dot(h, l)));
+  return l;
+}
+
+// ---------------------------------------------------------------- sample bookkeeping (main():597-612)
+__device__ __forceinline__ vec3 clamp_radiance(vec3 c) {
+  return mk(gmin(gmax(c.x, 0.0f), kClamp), gmin(gmax(c.y, 0.0f), kClamp), gmin(gmax(c.z, 0.0f), kClamp));
+}
+
+// End of trace() (main.comp:580-582) + NaN filter (:607-612, tested before the clamp: Q12).
+// accum.xyz = sum of valid samples, accum.w = number of dropped (NaN) samples.
+__device__ __forceinline__ void finish_sample(vec3 color, vec3 indirect, vec3 bg_linear, float4& accum, Tally& tally) {
+  const vec3 c = color + indirect * bg_linear;
+  if (any_nan(c)) {
+    accum.w += 1.0f;
+    ++tally.nans;
+  } else {
+    const vec3 cc = clamp_radiance(c);
+    accum.x += cc.x;
+    accum.y += cc.y;
+    accum.z += cc.z;
+  }
+}
+
+// slot <-> pixel: slots are 8x8 pixel tiles (64 consecutive slots = one wave = one tile)
+__device__ __forceinline__ bool slot_to_pixel(const pt_dev_frame& f, uint32_t slot, uint32_t& x, uint32_t& y) {
+  const uint32_t tile = slot >> 6, in = slot & 63u;
+  const uint32_t ty = tile / f.tiles_x, tx = tile - ty * f.tiles_x;
+  x = tx * 8u + (in & 7u);
+  y = ty * 8u + (in >> 3);
+  return x < f.pc.resolution_x && y < f.pc.resolution_y;
+}
+
+// Camera ray of stratum `sample` (main():599-605). Draws the x jitter first, then y.
+__device__ __forceinline__ void camera_ray(const pt_dev_frame& f, uint32_t x, uint32_t y, uint32_t sample, uint32_t& rng,
+                                           vec3& origin, vec3& dir) {
+  const uint32_t n = f.sqrt_samples;
+  const uint32_t sub_i = sample / n, sub_j = sample - sub_i * n;
+  const float fn = static_cast<float>(n);
+  const float jx = (static_cast<float>(sub_i) + rand_float(rng)) / fn;
+  const float jy = (static_cast<float>(sub_j) + rand_float(rng)) / fn;
+  const vec3 corner = mk(f.pc.corner_pixel_pos[0], f.pc.corner_pixel_pos[1], f.pc.corner_pixel_pos[2]);
+  const vec3 du = mk(f.pc.pixel_delta_u[0], f.pc.pixel_delta_u[1], f.pc.pixel_delta_u[2]);
+  const vec3 dv = mk(f.pc.pixel_delta_v[0], f.pc.pixel_delta_v[1], f.pc.pixel_delta_v[2]);
+  const vec3 pixel_center = corner + (static_cast<float>(x) + jx) * du + (static_cast<float>(y) + jy) * dv;
+  origin = mk(f.pc.camera_position[0], f.pc.camera_position[1], f.pc.camera_position[2]);
+  dir = normalize(pixel_center - origin);
+}
+
+}  // namespace
+
+// =========================================================================== kernels
+
+// First sample of every slot; fills queue 0 with the live slots (compacted: padding slots
+// of partial tiles never enter a queue).
+__global__ __launch_bounds__(256) void k_init(pt_dev_frame f, pt_dev_state st) {
+  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t x = 0, y = 0;
+  bool live = slot < f.slot_count && slot_to_pixel(f, slot, x, y) && f.sample_begin < f.sample_end;
+  Tally tally;
+  if (slot < f.slot_count) {
+    st.accum[slot] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    st.primary_id[slot] = kNoHit;
+  }
+  if (live) {
+    const uint32_t index = y * f.pc.resolution_x + x;
+    uint32_t rng = index ^ f.pc.seed;  // main.comp:592
+    if (f.num_ranks > 1) rng = triple32(index ^ f.pc.seed ^ (0x9E3779B9u * (f.rank + 1u)));
+    vec3 o, d;
+    camera_ray(f, x, y, f.sample_begin, rng, o, d);
+    ++tally.paths;
+    st.ray_o[slot] = make_float4(o.x, o.y, o.z, 0.0f);
+    st.ray_d[slot] = make_float4(d.x, d.y, d.z, 0.0f);
+    st.path_a[slot] = make_float4(1.0f, 1.0f, 1.0f, ubits(rng));
+    st.path_b[slot] = make_float4(0.0f, 0.0f, 0.0f, ubits(ctr_pack(0, 0, true, f.sample_begin)));
+  }
+  const uint32_t at = wave_append(live, &st.counters[PT_CNT_QUEUE0]);
+  if (live) st.queue[0][at] = slot;
+  flush_tally(tally, st.stats);
+}
+
+// Closest hit for every queued ray.
+__global__ __launch_bounds__(256) void k_extend(pt_dev_scene sc, pt_dev_state st, uint32_t parity) {
+  extern __shared__ uint32_t lds_stack[];
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t n = st.counters[PT_CNT_QUEUE0 + parity];
+  if (gid == 0) {  // recycle the counters the previous iteration consumed
+    st.counters[PT_CNT_QUEUE0 + (parity ^ 1u)] = 0;
+    st.counters[PT_CNT_SHADOW] = 0;
+  }
+  Tally tally;
+  if (gid < n) {
+    const uint32_t slot = st.queue[parity][gid];
+    const float4 o4 = st.ray_o[slot], d4 = st.ray_d[slot];
+    Hit h{kInfinity, 0.0f, 0.0f, kNoHit};
+    closest_hit(sc.nodes, sc.tri_pos, xyz(o4), xyz(d4), h, lds_stack + threadIdx.x, blockDim.x, tally);
+    st.hit[slot] = make_uint4(h.tri, fbits(h.u), fbits(h.v), fbits(h.t));
+  }
+  flush_tally(tally, st.stats);
+}
+
+// trace() loop body for every extended ray.
+__global__ __launch_bounds__(256) void k_shade(pt_dev_scene sc, pt_dev_frame f, pt_dev_state st, uint32_t parity) {
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t n = st.counters[PT_CNT_QUEUE0 + parity];
+  const bool active = gid < n;
+  Tally tally;
+  bool alive = false;       // slot continues with a ray next iteration
+  bool wants_shadow = false;
+  uint32_t slot = 0;
+
+  if (active) {
+    slot = st.queue[parity][gid];
+    const uint4 hw = st.hit[slot];
+    const float4 pa = st.path_a[slot];
+    float4 pb = st.path_b[slot];
+    vec3 indirect = xyz(pa);
+    uint32_t rng = fbits(pa.w);
+    vec3 color = xyz(pb);
+    uint32_t ctr = fbits(pb.w);
+    uint32_t light_steps = ctr_light(ctr), transp_steps = ctr_transp(ctr), sample = ctr_sample(ctr);
+    const vec3 bg_linear = mk(f.bg_linear[0], f.bg_linear[1], f.bg_linear[2]);
+
+    if (ctr_primary(ctr)) st.primary_id[slot] = hw.x;
+
+    bool path_done = false;     // the sample ends at this vertex
+    bool deferred_finish = false;  // ... and k_shadow finishes it (it owns `color` then)
+    vec3 next_o = mk(0, 0, 0), next_d = mk(0, 0, 0);
+
+    if (hw.x == kNoHit) {  // main.comp:517 -> :580
+      float4 acc = st.accum[slot];
+      finish_sample(color, indirect, bg_linear, acc, tally);
+      st.accum[slot] = acc;
+      path_done = true;
+    } else {
+      const float4 d4 = st.ray_d[slot];
+      const vec3 ray_dir = xyz(d4);
+      const float hu = ubits(hw.y), hv = ubits(hw.z);
+      const vec3 wuv = mk(1.0f - hu - hv, hu, hv);
+      vec3 pos, nrm;
+      float tu, tv;
+      uint32_t mat_idx;
+      interpolate_pos_uv(sc, hw.x, wuv, pos, tu, tv, mat_idx, &nrm, tally);
+      if (dot(nrm, ray_dir) > 0.0f) nrm = nrm * -1.0f;  // main.comp:524
+
+      // get_material_data, main.comp:242-259
+      const Material m = load_material(sc.materials, mat_idx);
+      const float4 bc = sample_texture(sc, m.base_tex, tu, tv, tally);
+      const vec3 base_color = mk(m.base_color.x, m.base_color.y, m.base_color.z) * decode_srgb(m.base_tex, bc);
+      const float alpha = m.base_color.w * bc.w;
+      const float4 mr = sample_texture(sc, m.mr_tex, tu, tv, tally);
+      const float metal = m.metallic * mr.z;
+      const float roughness = m.roughness * mr.y;
+      const float4 em = sample_texture(sc, m.emissive_tex, tu, tv, tally);
+      const vec3 emission = m.emissive * decode_srgb(m.emissive_tex, em);
+      const float4 oc = sample_texture(sc, m.occlusion_tex, tu, tv, tally);
+      const float occlusion = 1.0f + m.occlusion_strength * (oc.x - 1.0f);
+      const float a = roughness * roughness;
+      const float a2 = a * a;
+      ++tally.verts;
+
+      const vec3 view = -ray_dir;
+      const vec3 shadow_origin = pos + kNormalDelta * nrm;
+      const uint32_t n_lights = sc.directional_light_count + sc.point_light_count + (f.pc.emissive_triangle_count ? 1u : 0u);
+      float4* rec = st.shadow_rec + 4 * static_cast<size_t>(slot) * n_lights;
+
+      // sample_punctual_light set-up, main.comp:409-457: everything up to the shadow walk
+      for (uint32_t i = 0; i < sc.directional_light_count; ++i) {
+        const float4 l0 = sc.directional_lights[2 * i], l1 = sc.directional_lights[2 * i + 1];
+        const vec3 l = -xyz(l1);
+        const float n_dot_l = gmax(dot(nrm, l), 0.0f);
+        const vec3 radiance = xyz(l0) * l0.w;
+        const vec3 brdf = microfacet_brdf(nrm, view, l, metal, a2, base_color);
+        rec[0] = make_float4(l.x, l.y, l.z, -__builtin_inff());  // no distance test for directional lights
+        rec[1] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
+        rec[2] = make_float4(brdf.x, brdf.y, brdf.z, n_dot_l);
+        rec[3] = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+        rec += 4;
+      }
+      for (uint32_t i = 0; i < sc.point_light_count; ++i) {
+        const float4 l0 = sc.point_lights[2 * i], l1 = sc.point_lights[2 * i + 1];
+        const vec3 lpos = xyz(l1);
+        const vec3 sample_dir = uniform_hemisphere_sampling(normalize(pos - lpos), rng);
+        const vec3 sample_pos = lpos + sample_dir * kPointLightRadius;
+        vec3 l = sample_pos - pos;
+        const float dist2 = dot(l, l);
+        l = normalize(l);
+        const float correction = kNormalDelta / dot(l, nrm);
+        const vec3 radiance = xyz(l0) * l0.w / kLightArea / kFourPi;
+        const float cos_theta0 = dot(sample_dir, -l);
+        const float pdf = dist2 / (cos_theta0 * kLightArea);
+        const float n_dot_l = __builtin_fabsf(dot(nrm, l));
+        const vec3 brdf = microfacet_brdf(nrm, view, l, metal, a2, base_color);
+        rec[0] = make_float4(l.x, l.y, l.z, length(pos - sample_pos));
+        rec[1] = make_float4(radiance.x, radiance.y, radiance.z, correction);
+        rec[2] = make_float4(brdf.x, brdf.y, brdf.z, n_dot_l);
+        rec[3] = make_float4(pdf, 0.0f, 0.0f, 0.0f);
+        rec += 4;
+      }
+      // sample_area_light set-up, main.comp:464-500
+      if (f.pc.emissive_triangle_count) {
+        const uint32_t count = f.pc.emissive_triangle_count;
+        uint32_t pick = static_cast<uint32_t>(rand_float(rng) * static_cast<float>(count));
+        if (pick > count - 1) pick = count - 1;  // Q3: rand_float may be exactly 1.0
+        const uint32_t etri = sc.emissive_triangles[pick];
+        float su = rand_float(rng), sv = rand_float(rng);  // sample_triangle, main.comp:158-165
+        if (su + sv > 1.0f) {
+          su = 1.0f - su;
+          sv = 1.0f - sv;
+        }
+        const vec3 ewuv = mk(1.0f - su - sv, su, sv);
+        vec3 tri_pos, tri_n;
+        float eu, ev;
+        uint32_t emat_idx;
+        interpolate_pos_uv(sc, etri, ewuv, tri_pos, eu, ev, emat_idx, &tri_n, tally);
+        vec3 l = tri_pos - pos;
+        const float dist2 = dot(l, l);
+        l = normalize(l);
+        if (dot(l, tri_n) > 0.0f) tri_n = tri_n * -1.0f;
+        const float correction = kNormalDelta / dot(l, nrm);
+        const float4 q0 = sc.tri_pos[3 * static_cast<size_t>(etri)];
+        const float4 q1 = sc.tri_pos[3 * static_cast<size_t>(etri) + 1];
+        const float4 q2 = sc.tri_pos[3 * static_cast<size_t>(etri) + 2];
+        const float area = length(cross(xyz(q1) - xyz(q0), xyz(q2) - xyz(q0))) / 2.0f;
+        const float cos_theta0 = dot(tri_n, -l);
+        const float pdf = dist2 / (cos_theta0 * area) / static_cast<float>(count);
+        const float n_dot_l = __builtin_fabsf(dot(nrm, l));
+        const Material emat = load_material(sc.materials, emat_idx);
+        const float4 et = sample_texture(sc, emat.emissive_tex, eu, ev, tally);
+        const vec3 e_emission = emat.emissive * decode_srgb(emat.emissive_tex, et);
+        const vec3 brdf = microfacet_brdf(nrm, view, l, metal, a2, base_color);
+        rec[0] = make_float4(l.x, l.y, l.z, length(pos - tri_pos));
+        rec[1] = make_float4(e_emission.x, e_emission.y, e_emission.z, correction);
+        rec[2] = make_float4(brdf.x, brdf.y, brdf.z, n_dot_l);
+        rec[3] = make_float4(pdf, 0.0f, 0.0f, 0.0f);
+      }
+
+      const vec3 indirect_pre = indirect * occlusion;  // main.comp:540
+      indirect = indirect_pre;
+      float weight;  // `alpha` on the pass-through branch, 1 otherwise (1 * x == x)
+      if (alpha < 1.0f && transp_steps < kMaxTransparencySteps) {  // main.comp:542-547
+        ++transp_steps;
+        weight = alpha;
+        indirect = indirect * (1.0f - alpha);
+        next_o = pos + kNormalDelta * ray_dir;
+        next_d = ray_dir;
+      } else {  // main.comp:549-577
+        ++light_steps;
+        weight = 1.0f;
+        float diffuse_pdf, microfacet_pdf;
+        const vec3 diffuse_dir = diffuse_sample(nrm, rng, diffuse_pdf);
+        const vec3 microfacet_dir = microfacet_sample(nrm, view, a2, rng, microfacet_pdf);
+        vec3 dir;
+        float c;
+        if (rand_float(rng) < metal) {
+          dir = microfacet_dir;
+          c = metal;
+        } else {
+          dir = diffuse_dir;
+          c = 1.0f - metal;
+        }
+        const float pdf = c * (diffuse_pdf + microfacet_pdf);
+        const float n_dot_l = gmax(dot(nrm, dir), 0.0f);
+        indirect = indirect * (microfacet_brdf(nrm, view, dir, metal, a2, base_color) * n_dot_l / pdf);
+        next_o = shadow_origin;
+        next_d = dir;
+      }
+      path_done = light_steps >= kMaxLightSteps;  // main.comp:512
+
+      if (n_lights == 0) {
+        // no light of any kind: direct = emission + vec3(0) + vec3(0) (main.comp:536-538)
+        const vec3 direct = (emission + splat(0.0f)) + splat(0.0f);
+        color = color + direct * weight * indirect_pre;  // :545 / :552
+        if (path_done) {
+          float4 acc = st.accum[slot];
+          finish_sample(color, indirect, bg_linear, acc, tally);
+          st.accum[slot] = acc;
+        }
+      } else {
+        wants_shadow = true;
+        deferred_finish = path_done;
+        float4* hdr = st.shadow_hdr + 4 * static_cast<size_t>(slot);
+        hdr[0] = make_float4(emission.x, emission.y, emission.z, weight);
+        hdr[1] = make_float4(indirect_pre.x, indirect_pre.y, indirect_pre.z, path_done ? 1.0f : 0.0f);
+        hdr[2] = make_float4(indirect.x, indirect.y, indirect.z, 0.0f);
+        hdr[3] = make_float4(shadow_origin.x, shadow_origin.y, shadow_origin.z, 0.0f);
+      }
+    }
+
+    if (path_done) {  // next stratum of this pixel, or retire the slot (main():597-598)
+      ++sample;
+      if (sample < f.sample_end) {
+        uint32_t x, y;
+        slot_to_pixel(f, slot, x, y);
+        camera_ray(f, x, y, sample, rng, next_o, next_d);
+        ++tally.paths;
+        alive = true;
+      }
+      indirect = splat(1.0f);
+      if (!deferred_finish) color = splat(0.0f);  // otherwise k_shadow still needs it and zeroes it itself
+      light_steps = 0;
+      transp_steps = 0;
+    } else {
+      alive = true;
+    }
+
+    if (alive) {
+      st.ray_o[slot] = make_float4(next_o.x, next_o.y, next_o.z, 0.0f);
+      st.ray_d[slot] = make_float4(next_d.x, next_d.y, next_d.z, 0.0f);
+    }
+    st.path_a[slot] = make_float4(indirect.x, indirect.y, indirect.z, ubits(rng));
+    pb = make_float4(color.x, color.y, color.z, ubits(ctr_pack(light_steps, transp_steps, false, sample)));
+    st.path_b[slot] = pb;
+  }
+
+  // queue compaction (all 64 lanes converge here)
+  const uint32_t at_next = wave_append(alive, &st.counters[PT_CNT_QUEUE0 + (parity ^ 1u)]);
+  if (alive) st.queue[parity ^ 1u][at_next] = slot;
+  const uint32_t at_shadow = wave_append(wants_shadow, &st.counters[PT_CNT_SHADOW]);
+  if (wants_shadow) st.shadow_queue[at_shadow] = slot;
+  flush_tally(tally, st.stats);
+}
+
+// ray_scene_intersect_with_transparency, main.comp:306-332. Returns the transparency and
+// leaves the last traversal's result in h.
+__device__ __forceinline__ float shadow_walk(const pt_dev_scene& sc, vec3 origin, vec3 dir, Hit& h, uint32_t* stack,
+                                             uint32_t stride, Tally& tally) {
+  float transparency = 1.0f;
+  for (uint32_t step = 0; step < kMaxTransparencySteps; ++step) {
+    h.t = kInfinity;
+    h.tri = kNoHit;
+    closest_hit(sc.nodes, sc.tri_pos, origin, dir, h, stack, stride, tally);
+    if (h.tri == kNoHit) break;
+    const vec3 wuv = mk(1.0f - h.u - h.v, h.u, h.v);
+    vec3 pos;
+    float tu, tv;
+    uint32_t mat_idx;
+    interpolate_pos_uv(sc, h.tri, wuv, pos, tu, tv, mat_idx, nullptr, tally);
+    const float4 base = sc.materials[4 * static_cast<size_t>(mat_idx)];
+    const int base_tex = static_cast<int>(fbits(sc.materials[4 * static_cast<size_t>(mat_idx) + 1].x));
+    const float alpha = base.w * sample_texture(sc, base_tex, tu, tv, tally).w;
+    if (alpha == 1.0f) return 0.0f;  // any opaque closest hit, at any distance (Q5)
+    transparency *= 1.0f - alpha;
+    origin = pos + kNormalDelta * dir;
+  }
+  return transparency;
+}
+
+// Shadow walks of one path vertex + the direct-lighting accumulate; finishes the sample
+// when the vertex was the path's last (light step 8).
+__global__ __launch_bounds__(256) void k_shadow(pt_dev_scene sc, pt_dev_frame f, pt_dev_state st) {
+  extern __shared__ uint32_t lds_stack[];
+  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t n = st.counters[PT_CNT_SHADOW];
+  Tally tally;
+  if (gid < n) {
+    const uint32_t slot = st.shadow_queue[gid];
+    const float4* hdr = st.shadow_hdr + 4 * static_cast<size_t>(slot);
+    const float4 h0 = hdr[0], h1 = hdr[1], h3 = hdr[3];
+    const vec3 origin = xyz(h3);
+    const uint32_t n_punctual = sc.directional_light_count + sc.point_light_count;
+    const uint32_t n_lights = n_punctual + (f.pc.emissive_triangle_count ? 1u : 0u);
+    const float4* rec = st.shadow_rec + 4 * static_cast<size_t>(slot) * n_lights;
+    uint32_t* stack = lds_stack + threadIdx.x;
+
+    vec3 punctual = splat(0.0f);  // sample_punctual_light's `color`, main.comp:410
+    vec3 area = splat(0.0f);
+    for (uint32_t k = 0; k < n_lights; ++k, rec += 4) {
+      const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
+      Hit h{kInfinity, 0.0f, 0.0f, kNoHit};
+      const float transparency = shadow_walk(sc, origin, xyz(r0), h, stack, blockDim.x, tally);
+      if (transparency == 0.0f) continue;                                   // :423 / :446 / :486
+      if (h.tri != kNoHit && h.t + r1.w < r0.w) continue;                   // :448 / :488
+      const vec3 c = (xyz(r1) * transparency) * xyz(r2) * r2.w / r3.x;      // :427 / :456 / :499-500
+      if (k < n_punctual) punctual = punctual + c;
+      else area = c;
+    }
+    vec3 direct = xyz(h0);          // emission, :536
+    direct = direct + punctual;     // :537
+    direct = direct + area;         // :538
+
+    float4 pb = st.path_b[slot];
+    vec3 color = xyz(pb) + direct * h0.w * xyz(h1);  // :545 / :552
+    if (h1.w != 0.0f) {
+      const float4 h2 = hdr[2];
+      float4 acc = st.accum[slot];
+      finish_sample(color, xyz(h2), mk(f.bg_linear[0], f.bg_linear[1], f.bg_linear[2]), acc, tally);
+      st.accum[slot] = acc;
+      color = splat(0.0f);
+    }
+    st.path_b[slot] = make_float4(color.x, color.y, color.z, pb.w);
+  }
+  flush_tally(tally, st.stats);
+}
+
+// slot order -> pixel order: accum_out = (sum R, sum G, sum B, valid samples)
+__global__ __launch_bounds__(256) void k_finalize(pt_dev_frame f, pt_dev_state st, float4* accum_out, uint32_t* primary_out) {
+  const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t x, y;
+  if (slot >= f.slot_count || !slot_to_pixel(f, slot, x, y)) return;
+  const uint32_t index = y * f.pc.resolution_x + x;
+  const float4 a = st.accum[slot];
+  const float valid = static_cast<float>(f.sample_end - f.sample_begin) - a.w;
+  accum_out[index] = make_float4(a.x, a.y, a.z, valid);
+  if (primary_out) primary_out[index] = st.primary_id[slot];
+}
+
+__device__ __forceinline__ uint32_t to_unorm8(float x) {  // imageStore to rgba8: NaN -> 0, round to nearest even
+  if (!(x > 0.0f)) return 0u;
+  if (x >= 1.0f) return 255u;
+  return static_cast<uint32_t>(__builtin_rintf(x * 255.0f));
+}
+
+// main():616-619
+__global__ __launch_bounds__(256) void k_resolve(const float4* __restrict__ accum, uint32_t pixel_count, uint32_t* __restrict__ rgba8) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= pixel_count) return;
+  const float4 a = accum[i];
+  const uint32_t r = to_unorm8(pt_pow(a.x / a.w, kInvGamma));
+  const uint32_t g = to_unorm8(pt_pow(a.y / a.w, kInvGamma));
+  const uint32_t b = to_unorm8(pt_pow(a.z / a.w, kInvGamma));
+  rgba8[i] = r | (g << 8) | (b << 16) | (255u << 24);
+}
+
+// =========================================================================== launchers
+
+namespace ptd {
+
+static inline uint32_t blocks_for(uint32_t n, uint32_t block) { return n ? (n + block - 1) / block : 1u; }
+
+void launch_init(const pt_dev_frame& f, const pt_dev_state& st, hipStream_t s) {
+  hipLaunchKernelGGL(k_init, dim3(blocks_for(f.slot_count, 256)), dim3(256), 0, s, f, st);
+}
+
+void launch_extend(const pt_dev_scene& sc, const pt_dev_state& st, uint32_t parity, uint32_t max_entries, uint32_t block,
+                   hipStream_t s) {
+  const size_t lds = static_cast<size_t>(block) * sc.stack_entries * sizeof(uint32_t);
+  hipLaunchKernelGGL(k_extend, dim3(blocks_for(max_entries, block)), dim3(block), lds, s, sc, st, parity);
+}
+
+void launch_shade(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity,
+                  uint32_t max_entries, hipStream_t s) {
+  hipLaunchKernelGGL(k_shade, dim3(blocks_for(max_entries, 256)), dim3(256), 0, s, sc, f, st, parity);
+}
+
+void launch_shadow(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t max_entries,
+                   uint32_t block, hipStream_t s) {
+  const size_t lds = static_cast<size_t>(block) * sc.stack_entries * sizeof(uint32_t);
+  hipLaunchKernelGGL(k_shadow, dim3(blocks_for(max_entries, block)), dim3(block), lds, s, sc, f, st);
+}
+
+void launch_finalize(const pt_dev_frame& f, const pt_dev_state& st, float4* accum_out, uint32_t* primary_out, hipStream_t s) {
+  hipLaunchKernelGGL(k_finalize, dim3(blocks_for(f.slot_count, 256)), dim3(256), 0, s, f, st, accum_out, primary_out);
+}
+
+void launch_resolve(const float4* accum, uint32_t pixel_count, uint32_t* rgba8, hipStream_t s) {
+  hipLaunchKernelGGL(k_resolve, dim3(blocks_for(pixel_count, 256)), dim3(256), 0, s, accum, pixel_count, rgba8);
+}
+
+}  // namespace ptd

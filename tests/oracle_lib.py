@@ -1,0 +1,44 @@
+"""Loader for the CPU oracle (oracle/_build/libpt_oracle.so). Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+_SO = os.path.join(ROOT, "oracle", "_build", "libpt_oracle.so")
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        src = os.path.join(ROOT, "oracle", "pt_oracle.c")
+        if not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+        _lib = C.CDLL(_SO)
+        _lib.orc_triple32.restype = C.c_uint32
+        _lib.orc_pow.restype = C.c_float
+        _lib.orc_pow.argtypes = [C.c_float, C.c_float]
+        _lib.orc_exp2.restype = C.c_float
+        _lib.orc_exp2.argtypes = [C.c_float]
+        _lib.orc_log2.restype = C.c_float
+        _lib.orc_log2.argtypes = [C.c_float]
+        _lib.orc_sincos.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        _lib.orc_render.restype = C.c_int
+    return _lib
+
+
+def render(lib, packed, rp, threads=8, rows=None, want_ids=True):
+    """orc_render over full image buffers; returns (rgba8, accum, ids, stats dict)."""
+    import numpy as np
+    from pathtracer_amd import abi
+    w, h = rp.pc.resolution_x, rp.pc.resolution_y
+    rgba = np.zeros((h, w, 4), dtype=np.uint8)
+    accum = np.zeros((h, w, 4), dtype=np.float32)
+    ids = np.full((h, w), 0xFFFFFFFF, dtype=np.uint32)
+    st = abi.Stats()
+    y0, y1 = rows if rows else (0, h)
+    rc = lib.orc_render(C.byref(packed.desc), C.byref(rp), abi.ptr(rgba), abi.ptr(accum),
+                        abi.ptr(ids) if want_ids else None, C.byref(st), C.c_int(threads),
+                        C.c_uint32(y0), C.c_uint32(y1))
+    assert rc == 0
+    return rgba, accum, ids, st.as_dict()
