@@ -322,7 +322,7 @@ __device__ __forceinline__ float distribution_ggx(float n_dot_h, float a2) {
 __device__ __forceinline__ float geometry_smith1(vec3 n, vec3 h, vec3 x, float a2) {
   if (dot(h, x) <= 0.0f) return 0.0f;
   const float n_dot_x = dot(n, x);
-  const float denom = __builtin_fabsf(n_dot_x) + __fsqrt_rn(a2 + (1.0f - a2) * n_dot_x * n_dot_x);
+  const float denom = __builtin_fabsf(n_dot_x) + __builtin_sqrtf(a2 + (1.0f - a2) * n_dot_x * n_dot_x);
   return 1.0f / denom;
 }
 
@@ -355,7 +355,7 @@ __device__ __forceinline__ vec3 to_world(const Basis& b, vec3 p) { return mat3_m
 __device__ __forceinline__ vec3 uniform_hemisphere_sampling(vec3 n, uint32_t& rng) {
   const float phi = 2.0f * kPi * rand_float(rng);
   const float cos_theta = 1.0f - rand_float(rng);
-  const float sin_theta = __fsqrt_rn(1.0f - cos_theta * cos_theta);
+  const float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
   float sp, cp;
   pt_sincos(phi, &sp, &cp);
   return to_world(orthogonal_matrix(n), mk(cp * sin_theta, sp * sin_theta, cos_theta));
@@ -366,8 +366,8 @@ __device__ __forceinline__ vec3 diffuse_sample(vec3 n, uint32_t& rng, float& pdf
   const float rnd = rand_float(rng);
   float sp, cp;
   pt_sincos(phi, &sp, &cp);
-  const float sr = __fsqrt_rn(rnd);
-  const vec3 l = to_world(orthogonal_matrix(n), mk(cp * sr, sp * sr, __fsqrt_rn(1.0f - rnd)));
+  const float sr = __builtin_sqrtf(rnd);
+  const vec3 l = to_world(orthogonal_matrix(n), mk(cp * sr, sp * sr, __builtin_sqrtf(1.0f - rnd)));
   pdf = gmax(dot(n, l), 0.0f) / kPi;
   return l;
 }
@@ -376,8 +376,8 @@ __device__ __forceinline__ vec3 microfacet_sample(vec3 n, vec3 v, float a2, uint
   const float phi = 2.0f * kPi * rand_float(rng);
   const float rnd = rand_float(rng);
   const float cos2_theta = gmin(gmax((1.0f - rnd) / (rnd * (a2 - 1.0f) + 1.0f), 0.0f), 1.0f);
-  const float cos_theta = __fsqrt_rn(cos2_theta);
-  const float sin_theta = __fsqrt_rn(1.0f - cos2_theta);
+  const float cos_theta = __builtin_sqrtf(cos2_theta);
+  const float sin_theta = __builtin_sqrtf(1.0f - cos2_theta);
   float sp, cp;
   pt_sincos(phi, &sp, &cp);
   const vec3 h = normalize(to_world(orthogonal_matrix(n), mk(cp * sin_theta, sp * sin_theta, cos_theta)));
@@ -610,12 +610,11 @@ __global__ __launch_bounds__(256) void k_shade(pt_dev_scene sc, pt_dev_frame f, 
         const float cos_theta0 = dot(tri_n, -l);
         const float pdf = dist2 / (cos_theta0 * area) / static_cast<float>(count);
         const float n_dot_l = __builtin_fabsf(dot(nrm, l));
-        const Material emat = load_material(sc.materials, emat_idx);
-        const float4 et = sample_texture(sc, emat.emissive_tex, eu, ev, tally);
-        const vec3 e_emission = emat.emissive * decode_srgb(emat.emissive_tex, et);
         const vec3 brdf = microfacet_brdf(nrm, view, l, metal, a2, base_color);
+        // the emitter's emission (material + texture fetch, main.comp:497-498) is only
+        // evaluated if the shadow walk lets the sample through: k_shadow does it
         rec[0] = make_float4(l.x, l.y, l.z, length(pos - tri_pos));
-        rec[1] = make_float4(e_emission.x, e_emission.y, e_emission.z, correction);
+        rec[1] = make_float4(eu, ev, ubits(emat_idx), correction);
         rec[2] = make_float4(brdf.x, brdf.y, brdf.z, n_dot_l);
         rec[3] = make_float4(pdf, 0.0f, 0.0f, 0.0f);
       }
@@ -756,7 +755,13 @@ __global__ __launch_bounds__(256) void k_shadow(pt_dev_scene sc, pt_dev_frame f,
       const float transparency = shadow_walk(sc, origin, xyz(r0), h, stack, blockDim.x, tally);
       if (transparency == 0.0f) continue;                                   // :423 / :446 / :486
       if (h.tri != kNoHit && h.t + r1.w < r0.w) continue;                   // :448 / :488
-      const vec3 c = (xyz(r1) * transparency) * xyz(r2) * r2.w / r3.x;      // :427 / :456 / :499-500
+      vec3 radiance = xyz(r1);
+      if (k >= n_punctual) {  // area light: emission of the sampled emitter, main.comp:497-498
+        const Material emat = load_material(sc.materials, fbits(r1.z));
+        const float4 et = sample_texture(sc, emat.emissive_tex, r1.x, r1.y, tally);
+        radiance = emat.emissive * decode_srgb(emat.emissive_tex, et);
+      }
+      const vec3 c = (radiance * transparency) * xyz(r2) * r2.w / r3.x;     // :427 / :456 / :499-500
       if (k < n_punctual) punctual = punctual + c;
       else area = c;
     }

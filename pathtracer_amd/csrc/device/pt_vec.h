@@ -36,10 +36,10 @@ __device__ __forceinline__ vec3 cross(vec3 a, vec3 b) {
 }
 // GLSL normalize(): v * inversesqrt(dot(v, v)), inversesqrt(x) = 1 / sqrt(x) (both IEEE)
 __device__ __forceinline__ vec3 normalize(vec3 a) {
-  float inv = 1.0f / __fsqrt_rn(dot(a, a));
+  float inv = 1.0f / __builtin_sqrtf(dot(a, a));
   return a * inv;
 }
-__device__ __forceinline__ float length(vec3 a) { return __fsqrt_rn(dot(a, a)); }
+__device__ __forceinline__ float length(vec3 a) { return __builtin_sqrtf(dot(a, a)); }
 
 // GLSL min/max with the NaN rule this build fixes: a NaN operand is dropped
 // (v_min_f32 / v_max_f32, C fminf / fmaxf).
