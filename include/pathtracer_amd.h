@@ -194,6 +194,17 @@ typedef struct pt_render_params {
   uint32_t flags;       /* reserved, 0 */
 } pt_render_params;
 
+/* Per-kernel slice of the work counters (with PT_FLAG_TIME_KERNELS also its device time). */
+typedef struct pt_kernel_stats {
+  uint64_t launches;
+  uint64_t rays;         /* traversals started by this kernel            */
+  uint64_t node_visits;
+  uint64_t tri_tests;
+  uint64_t hits_shaded;
+  uint64_t texture_taps;
+  double   ms;           /* sum of the launches' durations (HIP events on the launch stream) */
+} pt_kernel_stats;
+
 /* Work counters of one render, SURVEY.md §8d definitions. */
 typedef struct pt_stats {
   uint64_t paths;          /* trace() calls (camera samples)                               */
@@ -206,10 +217,11 @@ typedef struct pt_stats {
   uint64_t nan_samples;    /* samples dropped by the NaN filter (main.comp:608-609)        */
   uint64_t iterations;     /* wavefront iterations launched                                */
   double   render_ms;      /* device time of the render loop (HIP events)                  */
-  double   trace_ms;       /* ... spent in the two traversal kernels (extend + shadow), when PT_FLAG_TIME_KERNELS */
-  double   shade_ms;       /* ... spent in the shade kernel, when PT_FLAG_TIME_KERNELS     */
   double   upload_ms;      /* last pt_upload_scene H2D time                                */
   double   download_ms;    /* last D2H of the outputs                                      */
+  pt_kernel_stats extend;  /* k_extend: closest hit of every path segment                  */
+  pt_kernel_stats shade;   /* k_shade: shading, light-sample set-up, regeneration, compaction */
+  pt_kernel_stats shadow;  /* k_shadow: shadow walks + direct-light accumulate             */
 } pt_stats;
 
 #define PT_FLAG_TIME_KERNELS 1u /* bracket every kernel with HIP events (serialises; for profiling) */

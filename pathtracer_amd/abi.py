@@ -158,17 +158,31 @@ class RenderParams(C.Structure):
     ]
 
 
+class KernelStats(C.Structure):
+    _fields_ = [
+        ("launches", C.c_uint64), ("rays", C.c_uint64), ("node_visits", C.c_uint64), ("tri_tests", C.c_uint64),
+        ("hits_shaded", C.c_uint64), ("texture_taps", C.c_uint64), ("ms", C.c_double),
+    ]
+
+    def as_dict(self) -> dict:
+        return {name: getattr(self, name) for name, _ in self._fields_}
+
+
 class Stats(C.Structure):
     _fields_ = [
         ("paths", C.c_uint64), ("rays", C.c_uint64), ("node_visits", C.c_uint64),
         ("tri_tests", C.c_uint64), ("hits_shaded", C.c_uint64), ("texture_taps", C.c_uint64),
         ("shaded_vertices", C.c_uint64), ("nan_samples", C.c_uint64), ("iterations", C.c_uint64),
-        ("render_ms", C.c_double), ("trace_ms", C.c_double), ("shade_ms", C.c_double),
-        ("upload_ms", C.c_double), ("download_ms", C.c_double),
+        ("render_ms", C.c_double), ("upload_ms", C.c_double), ("download_ms", C.c_double),
+        ("extend", KernelStats), ("shade", KernelStats), ("shadow", KernelStats),
     ]
 
     def as_dict(self) -> dict:
-        return {name: getattr(self, name) for name, _ in self._fields_}
+        d = {}
+        for name, _ in self._fields_:
+            v = getattr(self, name)
+            d[name] = v.as_dict() if isinstance(v, KernelStats) else v
+        return d
 
 
 FLAG_TIME_KERNELS = 1

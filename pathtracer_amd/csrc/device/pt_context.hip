@@ -186,7 +186,8 @@ int ensure_state(pt_ctx* ctx, uint32_t slots, uint32_t lights, uint32_t pixels) 
   ALLOC(st.queue[1], slots);
   ALLOC(st.shadow_queue, slots);
   ALLOC(st.counters, PT_CNT_WORDS);
-  ALLOC(st.stats, PT_ST_WORDS);
+  st.stat_rows = slots / 64 + 1;
+  ALLOC(st.stats, static_cast<size_t>(PT_K_COUNT) * st.stat_rows * PT_ST_WORDS);
   ALLOC(ctx->accum_out, pixels);
   ALLOC(ctx->primary_out, pixels);
   ALLOC(ctx->rgba8_out, pixels);
@@ -401,14 +402,16 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
   const uint32_t trace_block = (256u * sc.stack_entries * 4u <= 65536u) ? 256u : 64u;
   const bool time_kernels = (p->flags & PT_FLAG_TIME_KERNELS) != 0;
   size_t ev_used = 0;
-  std::vector<std::pair<size_t, int>> ev_kind;  // index of the start event, 0 = trace, 1 = shade
+  std::vector<std::pair<size_t, int>> ev_kind;  // index of the start event, kernel id
+  uint64_t launches[PT_K_COUNT] = {0, 0, 0, 0};
 
   PT_HIP(ctx, hipMemsetAsync(st.counters, 0, PT_CNT_WORDS * sizeof(uint32_t), stream));
-  PT_HIP(ctx, hipMemsetAsync(st.stats, 0, PT_ST_WORDS * sizeof(unsigned long long), stream));
+  PT_HIP(ctx, hipMemsetAsync(st.stats, 0, static_cast<size_t>(PT_K_COUNT) * st.stat_rows * PT_ST_WORDS * sizeof(unsigned long long), stream));
   PT_HIP(ctx, hipEventRecord(ctx->ev_start, stream));
   ptd::launch_init(f, st, stream);
 
   auto timed = [&](int kind, auto&& launch) {
+    ++launches[kind];
     if (time_kernels) {
       hipEvent_t a = next_kernel_event(ctx, ev_used);
       hipEvent_t b = next_kernel_event(ctx, ev_used);
@@ -434,9 +437,9 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
   while (!drained && iter < max_iters) {
     for (uint32_t b = 0; b < kBatch; ++b, ++iter) {
       const uint32_t parity = static_cast<uint32_t>(iter & 1u);
-      timed(0, [&] { ptd::launch_extend(sc, st, parity, bound, trace_block, stream); });
-      timed(1, [&] { ptd::launch_shade(sc, f, st, parity, bound, stream); });
-      if (n_lights) timed(0, [&] { ptd::launch_shadow(sc, f, st, bound, trace_block, stream); });
+      timed(PT_K_EXTEND, [&] { ptd::launch_extend(sc, st, parity, bound, trace_block, stream); });
+      timed(PT_K_SHADE, [&] { ptd::launch_shade(sc, f, st, parity, bound, stream); });
+      if (n_lights) timed(PT_K_SHADOW, [&] { ptd::launch_shadow(sc, f, st, bound, trace_block, stream); });
     }
     PT_HIP(ctx, hipGetLastError());
     // entries queued for the NEXT iteration; stays intact until that iteration's successor recycles it
@@ -463,26 +466,41 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
   PT_HIP(ctx, hipStreamSynchronize(stream));
 
   if (stats_out) {
-    unsigned long long h[PT_ST_WORDS];
-    PT_HIP(ctx, hipMemcpy(h, st.stats, sizeof(h), hipMemcpyDeviceToHost));
+    unsigned long long h[PT_K_COUNT][PT_ST_WORDS] = {};
+    {
+      std::vector<unsigned long long> rows(static_cast<size_t>(PT_K_COUNT) * st.stat_rows * PT_ST_WORDS);
+      PT_HIP(ctx, hipMemcpy(rows.data(), st.stats, rows.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+      for (int k = 0; k < PT_K_COUNT; ++k)
+        for (size_t r = 0; r < st.stat_rows; ++r)
+          for (int w = 0; w < PT_ST_WORDS; ++w) h[k][w] += rows[(static_cast<size_t>(k) * st.stat_rows + r) * PT_ST_WORDS + w];
+    }
     std::memset(stats_out, 0, sizeof(*stats_out));
-    stats_out->paths = h[PT_ST_PATHS];
-    stats_out->rays = h[PT_ST_RAYS];
-    stats_out->node_visits = h[PT_ST_VISITS];
-    stats_out->tri_tests = h[PT_ST_TESTS];
-    stats_out->hits_shaded = h[PT_ST_HITS];
-    stats_out->texture_taps = h[PT_ST_TAPS];
-    stats_out->shaded_vertices = h[PT_ST_VERTS];
-    stats_out->nan_samples = h[PT_ST_NANS];
+    auto total = [&](int w) { return h[PT_K_INIT][w] + h[PT_K_EXTEND][w] + h[PT_K_SHADE][w] + h[PT_K_SHADOW][w]; };
+    stats_out->paths = total(PT_ST_PATHS);
+    stats_out->rays = total(PT_ST_RAYS);
+    stats_out->node_visits = total(PT_ST_VISITS);
+    stats_out->tri_tests = total(PT_ST_TESTS);
+    stats_out->hits_shaded = total(PT_ST_HITS);
+    stats_out->texture_taps = total(PT_ST_TAPS);
+    stats_out->shaded_vertices = total(PT_ST_VERTS);
+    stats_out->nan_samples = total(PT_ST_NANS);
     stats_out->iterations = iter;
+    pt_kernel_stats* per[PT_K_COUNT] = {nullptr, &stats_out->extend, &stats_out->shade, &stats_out->shadow};
+    for (int k = PT_K_EXTEND; k < PT_K_COUNT; ++k) {
+      per[k]->launches = launches[k];
+      per[k]->rays = h[k][PT_ST_RAYS];
+      per[k]->node_visits = h[k][PT_ST_VISITS];
+      per[k]->tri_tests = h[k][PT_ST_TESTS];
+      per[k]->hits_shaded = h[k][PT_ST_HITS];
+      per[k]->texture_taps = h[k][PT_ST_TAPS];
+    }
     float ms = 0.0f;
     PT_HIP(ctx, hipEventElapsedTime(&ms, ctx->ev_start, ctx->ev_stop));
     stats_out->render_ms = ms;
     stats_out->upload_ms = ctx->upload_ms;
     for (auto& [idx, kind] : ev_kind) {
       float k = 0.0f;
-      if (hipEventElapsedTime(&k, ctx->kernel_events[idx], ctx->kernel_events[idx + 1]) == hipSuccess)
-        (kind == 0 ? stats_out->trace_ms : stats_out->shade_ms) += k;
+      if (hipEventElapsedTime(&k, ctx->kernel_events[idx], ctx->kernel_events[idx + 1]) == hipSuccess) per[kind]->ms += k;
     }
   }
   return PT_OK;

@@ -11,6 +11,8 @@
 enum { PT_CNT_QUEUE0 = 0, PT_CNT_QUEUE1 = 1, PT_CNT_SHADOW = 2, PT_CNT_WORDS = 4 };
 // stats[] words (unsigned long long), order of flush_tally()
 enum { PT_ST_PATHS = 0, PT_ST_RAYS, PT_ST_VISITS, PT_ST_TESTS, PT_ST_HITS, PT_ST_TAPS, PT_ST_VERTS, PT_ST_NANS, PT_ST_WORDS };
+// one block of PT_ST_WORDS per kernel
+enum { PT_K_INIT = 0, PT_K_EXTEND, PT_K_SHADE, PT_K_SHADOW, PT_K_COUNT };
 
 // The scene in HBM, split by who reads it:
 //   nodes      traversal only   — the reference's 32-byte PackedBVHNode array verbatim; a
@@ -61,7 +63,8 @@ struct pt_dev_state {
   uint32_t* queue[2];
   uint32_t* shadow_queue;
   uint32_t* counters;
-  unsigned long long* stats;
+  unsigned long long* stats;  // [kernel][stat_rows][PT_ST_WORDS]: one row per block index, no atomics
+  uint32_t stat_rows;         // >= the largest grid (slot_count / 64 + 1)
 };
 
 namespace ptd {

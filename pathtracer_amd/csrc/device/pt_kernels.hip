@@ -68,16 +68,42 @@ __device__ __forceinline__ uint32_t lane_id() {
   return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }
 
-// Compacting append: every lane of the wave must call it (converged). Returns the slot in
-// the destination queue for lanes with `pred`, one atomic per wave.
-__device__ __forceinline__ uint32_t wave_append(bool pred, uint32_t* counter) {
-  const uint64_t mask = __ballot(pred);
-  const uint32_t before =
-      __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
-  uint32_t base = 0;
-  if (lane_id() == 0 && mask != 0) base = atomicAdd(counter, static_cast<uint32_t>(__popcll(mask)));
-  base = __builtin_amdgcn_readfirstlane(base);
-  return base + before;
+__device__ __forceinline__ uint32_t wave_id() { return threadIdx.x >> 6; }
+
+__device__ __forceinline__ uint32_t mbcnt(uint64_t mask) {  // set bits of `mask` below this lane
+  return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(mask >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(mask), 0u));
+}
+
+// Queue compaction, two queues at once: ballot + mbcnt inside a wave, a 4-entry LDS scan
+// across the block's waves, ONE returning atomic per block and queue (a single hot word
+// saturates near 90 atomics/us on MI355X, so per-wave atomics would bound the kernel).
+// Every thread of the block must call it (converged). Blocks are 256 threads = 4 waves.
+struct AppendSlots {
+  uint32_t a, b;
+};
+__device__ __forceinline__ AppendSlots block_append2(bool pred_a, uint32_t* counter_a, bool pred_b, uint32_t* counter_b) {
+  __shared__ uint32_t wave_count[2][4];
+  __shared__ uint32_t block_base[2];
+  const uint64_t mask_a = __ballot(pred_a), mask_b = __ballot(pred_b);
+  const uint32_t w = wave_id(), lane = lane_id();
+  if (lane == 0) {
+    wave_count[0][w] = static_cast<uint32_t>(__popcll(mask_a));
+    wave_count[1][w] = static_cast<uint32_t>(__popcll(mask_b));
+  }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    const uint32_t q = threadIdx.x;
+    const uint32_t total = wave_count[q][0] + wave_count[q][1] + wave_count[q][2] + wave_count[q][3];
+    uint32_t* counter = q ? counter_b : counter_a;
+    block_base[q] = (total && counter) ? atomicAdd(counter, total) : 0u;
+  }
+  __syncthreads();
+  uint32_t off_a = block_base[0], off_b = block_base[1];
+  for (uint32_t i = 0; i < w; ++i) {
+    off_a += wave_count[0][i];
+    off_b += wave_count[1][i];
+  }
+  return AppendSlots{off_a + mbcnt(mask_a), off_b + mbcnt(mask_b)};
 }
 
 __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
@@ -89,12 +115,28 @@ struct Tally {  // per-thread work counters, flushed once per kernel
   uint32_t rays = 0, visits = 0, tests = 0, hits = 0, taps = 0, verts = 0, paths = 0, nans = 0;
 };
 
-__device__ __forceinline__ void flush_tally(const Tally& t, unsigned long long* stats) {
-  uint32_t v[8] = {t.paths, t.rays, t.visits, t.tests, t.hits, t.taps, t.verts, t.nans};
+// Work counters without atomics: wave reduction, LDS across the block's waves, then lanes
+// 0..7 of the block add the eight sums into the block's OWN row of the partial table
+// (stats[kernel][blockIdx.x][word]); launches are stream-ordered, so the read-modify-write
+// is race-free. The host sums the rows after the render.
+__device__ __forceinline__ void flush_tally(const Tally& t, const pt_dev_state& st, int kernel) {
+  __shared__ uint32_t part[4][PT_ST_WORDS];
+  uint32_t v[PT_ST_WORDS] = {t.paths, t.rays, t.visits, t.tests, t.hits, t.taps, t.verts, t.nans};
+  const uint32_t w = wave_id(), lane = lane_id();
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    uint32_t s = wave_sum(v[i]);
-    if (lane_id() == 0 && s) atomicAdd(&stats[i], static_cast<unsigned long long>(s));
+  for (int i = 0; i < PT_ST_WORDS; ++i) {
+    const uint32_t s = wave_sum(v[i]);
+    if (lane == 0) part[w][i] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < PT_ST_WORDS) {
+    const uint32_t waves = blockDim.x >> 6;
+    uint32_t s = 0;
+    for (uint32_t i = 0; i < waves; ++i) s += part[i][threadIdx.x];
+    if (s) {
+      unsigned long long* row = st.stats + (static_cast<size_t>(kernel) * st.stat_rows + blockIdx.x) * PT_ST_WORDS;
+      row[threadIdx.x] += s;
+    }
   }
 }
 
@@ -459,9 +501,9 @@ __global__ __launch_bounds__(256) void k_init(pt_dev_frame f, pt_dev_state st) {
     st.path_a[slot] = make_float4(1.0f, 1.0f, 1.0f, ubits(rng));
     st.path_b[slot] = make_float4(0.0f, 0.0f, 0.0f, ubits(ctr_pack(0, 0, true, f.sample_begin)));
   }
-  const uint32_t at = wave_append(live, &st.counters[PT_CNT_QUEUE0]);
-  if (live) st.queue[0][at] = slot;
-  flush_tally(tally, st.stats);
+  const AppendSlots at = block_append2(live, &st.counters[PT_CNT_QUEUE0], false, nullptr);
+  if (live) st.queue[0][at.a] = slot;
+  flush_tally(tally, st, PT_K_INIT);
 }
 
 // Closest hit for every queued ray.
@@ -481,7 +523,7 @@ __global__ __launch_bounds__(256) void k_extend(pt_dev_scene sc, pt_dev_state st
     closest_hit(sc.nodes, sc.tri_pos, xyz(o4), xyz(d4), h, lds_stack + threadIdx.x, blockDim.x, tally);
     st.hit[slot] = make_uint4(h.tri, fbits(h.u), fbits(h.v), fbits(h.t));
   }
-  flush_tally(tally, st.stats);
+  flush_tally(tally, st, PT_K_EXTEND);
 }
 
 // trace() loop body for every extended ray.
@@ -697,12 +739,11 @@ __global__ __launch_bounds__(256) void k_shade(pt_dev_scene sc, pt_dev_frame f, 
     st.path_b[slot] = pb;
   }
 
-  // queue compaction (all 64 lanes converge here)
-  const uint32_t at_next = wave_append(alive, &st.counters[PT_CNT_QUEUE0 + (parity ^ 1u)]);
-  if (alive) st.queue[parity ^ 1u][at_next] = slot;
-  const uint32_t at_shadow = wave_append(wants_shadow, &st.counters[PT_CNT_SHADOW]);
-  if (wants_shadow) st.shadow_queue[at_shadow] = slot;
-  flush_tally(tally, st.stats);
+  // queue compaction (the whole block converges here)
+  const AppendSlots at = block_append2(alive, &st.counters[PT_CNT_QUEUE0 + (parity ^ 1u)], wants_shadow, &st.counters[PT_CNT_SHADOW]);
+  if (alive) st.queue[parity ^ 1u][at.a] = slot;
+  if (wants_shadow) st.shadow_queue[at.b] = slot;
+  flush_tally(tally, st, PT_K_SHADE);
 }
 
 // ray_scene_intersect_with_transparency, main.comp:306-332. Returns the transparency and
@@ -780,7 +821,7 @@ __global__ __launch_bounds__(256) void k_shadow(pt_dev_scene sc, pt_dev_frame f,
     }
     st.path_b[slot] = make_float4(color.x, color.y, color.z, pb.w);
   }
-  flush_tally(tally, st.stats);
+  flush_tally(tally, st, PT_K_SHADOW);
 }
 
 // slot order -> pixel order: accum_out = (sum R, sum G, sum B, valid samples)
