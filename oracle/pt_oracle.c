@@ -371,6 +371,7 @@ typedef struct {
   const pt_push_constants* pc;
   uint32_t rand_state;
   uint32_t* stack;
+  int any_hit_shadows; /* ORC_FLAG_ANYHIT_OPAQUE_SHADOW and the scene is provably all-opaque */
   pt_stats st;
 } shctx;
 
@@ -550,8 +551,10 @@ static void get_material_data(shctx* c, uint32_t mat_idx, float tu, float tv, v3
   *occlusion = 1.0f + mat->occlusion_strength * (oc.r - 1.0f);
 }
 
-/* main.comp:263-304 */
-static void ray_scene_intersect(shctx* c, const ray_t* ray, isect_t* info) {
+/* main.comp:263-304.  any_hit != 0 is the checker's mirror of the HIP path's shadow-ray
+ * optimisation: stop at the first accepted triangle.  The visiting order is unchanged, so
+ * "a hit exists" is decided identically; only the visit/test counters shrink. */
+static void ray_scene_intersect_ex(shctx* c, const ray_t* ray, isect_t* info, int any_hit) {
   ++c->st.rays;
   const pt_packed_bvh_node* nodes = c->sc->bvh_nodes;
   uint32_t* stack = c->stack;
@@ -560,8 +563,10 @@ static void ray_scene_intersect(shctx* c, const ray_t* ray, isect_t* info) {
   while (top != 0) {
     const pt_packed_bvh_node* node = &nodes[stack[--top]];
     if (node->triangle_count > 0) {
-      for (uint32_t i = 0; i < node->triangle_count; ++i)
+      for (uint32_t i = 0; i < node->triangle_count; ++i) {
         ray_triangle_intersect(c, ray, node->left_or_begin + i, info);
+        if (any_hit && info->tri_idx != ORC_NO_HIT) return;
+      }
     } else {
       ++c->st.node_visits;
       const pt_packed_bvh_node* left = &nodes[node->left_or_begin];
@@ -588,10 +593,20 @@ static void ray_scene_intersect(shctx* c, const ray_t* ray, isect_t* info) {
   }
 }
 
+static void ray_scene_intersect(shctx* c, const ray_t* ray, isect_t* info) {
+  ray_scene_intersect_ex(c, ray, info, 0);
+}
+
 /* main.comp:306-332 */
 static float ray_scene_intersect_with_transparency(shctx* c, ray_t ray, isect_t* info) {
   float transparency = 1.0f;
   uint32_t step = 0;
+  if (c->any_hit_shadows) { /* every surface has alpha == 1: the first closest hit returns 0 (main.comp:325) */
+    info->t = ORC_INFINITY;
+    info->tri_idx = ORC_NO_HIT;
+    ray_scene_intersect_ex(c, &ray, info, 1);
+    return info->tri_idx == ORC_NO_HIT ? 1.0f : 0.0f;
+  }
   while (step < ORC_MAX_TRANSPARENCY_STEPS) {
     ++step;
     info->t = ORC_INFINITY;
@@ -947,6 +962,7 @@ typedef struct {
   uint32_t* primary_id;
   uint32_t y_begin, y_end;
   volatile uint32_t* next_row;
+  int any_hit_shadows;
   pt_stats st;
 } worker_arg;
 
@@ -956,6 +972,7 @@ static void* worker_main(void* p) {
   memset(&c, 0, sizeof(c));
   c.sc = w->sc;
   c.pc = &w->rp->pc;
+  c.any_hit_shadows = w->any_hit_shadows;
   c.stack = (uint32_t*)malloc(sizeof(uint32_t) * (w->sc->bvh_max_depth + 64)); /* main.comp:263-265 */
   for (;;) {
     uint32_t y = __sync_fetch_and_add(w->next_row, 1u);
@@ -968,14 +985,40 @@ static void* worker_main(void* p) {
   return NULL;
 }
 
+/* 1 iff no surface can ever report alpha != 1.0 in the shadow walk: every material has
+ * base_color_factor.a == 1 and either no base-colour texture or one that is sampled with
+ * the nearest filter from an image whose alpha bytes are all 255 (a bilinear blend of
+ * ones need not round to exactly 1.0). Mirrors the rule of pt_upload_scene. */
+int orc_scene_all_opaque(const pt_scene_desc* sc) {
+  for (uint32_t i = 0; i < sc->material_count; ++i) {
+    const pt_material* m = &sc->materials[i];
+    if (m->base_color_factor[3] != 1.0f) return 0;
+    if (m->base_color_texture_index == -1) continue;
+    const pt_texture* t = &sc->textures[m->base_color_texture_index];
+    if (sc->samplers[t->sampler_index].mag_filter != PT_FILTER_NEAREST) return 0;
+    const pt_image* im = &sc->images[t->image_index];
+    for (size_t k = 0; k < (size_t)im->width * im->height; ++k)
+      if (im->rgba8[4 * k + 3] != 255) return 0;
+  }
+  return 1;
+}
+
 int orc_render(const pt_scene_desc* scene, const pt_render_params* params, uint8_t* rgba8_out,
                float* accum_out, uint32_t* primary_id_out, pt_stats* stats_out, int num_threads,
                uint32_t y_begin, uint32_t y_end) {
+  return orc_render_ex(scene, params, rgba8_out, accum_out, primary_id_out, stats_out, num_threads, y_begin,
+                       y_end, 0);
+}
+
+int orc_render_ex(const pt_scene_desc* scene, const pt_render_params* params, uint8_t* rgba8_out,
+                  float* accum_out, uint32_t* primary_id_out, pt_stats* stats_out, int num_threads,
+                  uint32_t y_begin, uint32_t y_end, uint32_t flags) {
   if (!scene || !params) return -1;
   if (y_end > params->pc.resolution_y) y_end = params->pc.resolution_y;
   if (num_threads < 1) num_threads = 1;
   if (num_threads > 256) num_threads = 256;
   volatile uint32_t next_row = y_begin;
+  const int any_hit = (flags & ORC_FLAG_ANYHIT_OPAQUE_SHADOW) && orc_scene_all_opaque(scene);
   pthread_t th[256];
   worker_arg args[256];
   for (int i = 0; i < num_threads; ++i) {
@@ -983,6 +1026,7 @@ int orc_render(const pt_scene_desc* scene, const pt_render_params* params, uint8
     memset(w, 0, sizeof(*w));
     w->sc = scene; w->rp = params; w->rgba8 = rgba8_out; w->accum = accum_out;
     w->primary_id = primary_id_out; w->y_begin = y_begin; w->y_end = y_end; w->next_row = &next_row;
+    w->any_hit_shadows = any_hit;
     if (num_threads > 1) pthread_create(&th[i], NULL, worker_main, w);
     else worker_main(w);
   }

@@ -35,6 +35,16 @@ int orc_render(const pt_scene_desc* scene, const pt_render_params* params, uint8
                float* accum_out, uint32_t* primary_id_out, pt_stats* stats_out, int num_threads,
                uint32_t y_begin, uint32_t y_end);
 
+/* Same, with checker options. ORC_FLAG_ANYHIT_OPAQUE_SHADOW mirrors the HIP path's shadow-ray
+ * shortcut (first accepted hit ends the traversal when the scene is provably all-opaque):
+ * images are identical to orc_render by construction, only node_visits / tri_tests /
+ * hits_shaded differ; it exists so the GPU work counters can be checked for equality. */
+#define ORC_FLAG_ANYHIT_OPAQUE_SHADOW 1u
+int orc_render_ex(const pt_scene_desc* scene, const pt_render_params* params, uint8_t* rgba8_out,
+                  float* accum_out, uint32_t* primary_id_out, pt_stats* stats_out, int num_threads,
+                  uint32_t y_begin, uint32_t y_end, uint32_t flags);
+int orc_scene_all_opaque(const pt_scene_desc* scene);
+
 /* main.comp:616-619 for one pixel's accumulator */
 void orc_resolve_pixel(float r, float g, float b, float valid, uint8_t* out_rgba);
 

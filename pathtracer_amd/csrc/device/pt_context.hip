@@ -335,6 +335,27 @@ extern "C" int pt_upload_scene(pt_ctx* ctx, const pt_scene_desc* s) {
   if ((rc = dev_upload(ctx, ctx->scene_bufs, &d.texels, pool.data(), pool.size())) != PT_OK) return rc;
   if ((rc = dev_upload(ctx, ctx->scene_bufs, &d.textures, trec.data(), trec.size())) != PT_OK) return rc;
 
+  // Provably all-opaque scene: every material has base_color_factor.a == 1 and either no
+  // base-colour texture or one sampled with the nearest filter from an image whose alpha
+  // bytes are all 255 (a bilinear blend of ones need not round to exactly 1.0).
+  d.all_opaque = 1;
+  for (uint32_t i = 0; i < s->material_count && d.all_opaque; ++i) {
+    const pt_material& m = s->materials[i];
+    if (m.base_color_factor[3] != 1.0f) d.all_opaque = 0;
+    else if (m.base_color_texture_index != -1) {
+      const pt_texture& t = s->textures[m.base_color_texture_index];
+      if (s->samplers[t.sampler_index].mag_filter != PT_FILTER_NEAREST) d.all_opaque = 0;
+      else {
+        const pt_image& im = s->images[t.image_index];
+        const size_t n = static_cast<size_t>(im.width) * im.height;
+        for (size_t k = 0; k < n; ++k)
+          if (im.rgba8[4 * k + 3] != 255) {
+            d.all_opaque = 0;
+            break;
+          }
+      }
+    }
+  }
   d.directional_light_count = s->directional_light_count;
   d.point_light_count = s->point_light_count;
   d.stack_entries = depth + 1;

@@ -36,6 +36,7 @@ struct pt_dev_scene {
   uint32_t point_light_count;
   uint32_t stack_entries;            // LDS stack rows per lane (bvh_max_depth + 1)
   uint32_t triangle_count;
+  uint32_t all_opaque;               // 1: no surface can report alpha != 1 (shadow rays may stop at the first hit)
 };
 
 struct pt_dev_frame {

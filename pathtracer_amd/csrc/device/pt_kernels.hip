@@ -193,8 +193,12 @@ __device__ __forceinline__ bool ray_box(vec3 o, vec3 inv, const float4& bmin, co
 // The deferred far children live in an LDS stack, one column per lane
 // (stack[level * stride + lane]: conflict-free ds_read/ds_write_b32).
 // A sibling pair {2k, 2k+1} is one aligned 64-byte record (4 x float4).
-__device__ __forceinline__ void closest_hit(const float4* __restrict__ nodes, const float4* __restrict__ tri_pos,
-                                            vec3 o, vec3 d, Hit& h, uint32_t* stack, uint32_t stride, Tally& tally) {
+// ANY_HIT (shadow rays of provably all-opaque scenes): the traversal ends at the first
+// accepted triangle. The order is unchanged, so whether a hit exists is decided exactly as
+// by the full closest-hit search; h then holds *a* hit, not the closest.
+template <bool ANY_HIT>
+__device__ __forceinline__ void traverse(const float4* __restrict__ nodes, const float4* __restrict__ tri_pos,
+                                         vec3 o, vec3 d, Hit& h, uint32_t* stack, uint32_t stride, Tally& tally) {
   ++tally.rays;
   const vec3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
   uint32_t sp = 0;
@@ -202,8 +206,16 @@ __device__ __forceinline__ void closest_hit(const float4* __restrict__ nodes, co
   uint32_t cnt = fbits(nodes[1].w);
   for (;;) {
     if (cnt > 0) {
-      tally.tests += cnt;
-      for (uint32_t i = 0; i < cnt; ++i) ray_triangle(tri_pos, o, d, lob + i, h);
+      if (ANY_HIT) {
+        for (uint32_t i = 0; i < cnt; ++i) {
+          ++tally.tests;
+          ray_triangle(tri_pos, o, d, lob + i, h);
+          if (h.tri != kNoHit) return;
+        }
+      } else {
+        tally.tests += cnt;
+        for (uint32_t i = 0; i < cnt; ++i) ray_triangle(tri_pos, o, d, lob + i, h);
+      }
     } else {
       ++tally.visits;
       const float4* pair = nodes + 2 * static_cast<size_t>(lob);
@@ -231,6 +243,11 @@ __device__ __forceinline__ void closest_hit(const float4* __restrict__ nodes, co
     lob = fbits(nodes[2 * static_cast<size_t>(idx)].w);
     cnt = fbits(nodes[2 * static_cast<size_t>(idx) + 1].w);
   }
+}
+
+__device__ __forceinline__ void closest_hit(const float4* __restrict__ nodes, const float4* __restrict__ tri_pos,
+                                            vec3 o, vec3 d, Hit& h, uint32_t* stack, uint32_t stride, Tally& tally) {
+  traverse<false>(nodes, tri_pos, o, d, h, stack, stride, tally);
 }
 
 // ---------------------------------------------------------------- scene fetch
@@ -751,6 +768,12 @@ __global__ __launch_bounds__(256) void k_shade(pt_dev_scene sc, pt_dev_frame f, 
 __device__ __forceinline__ float shadow_walk(const pt_dev_scene& sc, vec3 origin, vec3 dir, Hit& h, uint32_t* stack,
                                              uint32_t stride, Tally& tally) {
   float transparency = 1.0f;
+  if (sc.all_opaque) {  // every closest hit has alpha == 1 and returns 0 (main.comp:325): any hit decides
+    h.t = kInfinity;
+    h.tri = kNoHit;
+    traverse<true>(sc.nodes, sc.tri_pos, origin, dir, h, stack, stride, tally);
+    return h.tri == kNoHit ? 1.0f : 0.0f;
+  }
   for (uint32_t step = 0; step < kMaxTransparencySteps; ++step) {
     h.t = kInfinity;
     h.tri = kNoHit;

@@ -103,7 +103,7 @@ def cornell_scene(with_point_light: bool = False, with_directional_light: bool =
     """cfg2: Cornell box — floor, ceiling, back wall, red/green side walls (open front),
     a short and a tall box, and an emissive ceiling quad: 5*2 + 2*12 + 2 = 36 triangles.
     Materials: 0 default, 1 white, 2 red, 3 green, 4 light (emissive 17,12,4), 5 metal,
-    6 glass (alpha 0.4)."""
+    6 glass (alpha 0.4, only with glass_pane)."""
     mats = np.concatenate([
         default_material(),
         make_material((0.73, 0.73, 0.73, 1.0)),
@@ -111,8 +111,7 @@ def cornell_scene(with_point_light: bool = False, with_directional_light: bool =
         make_material((0.12, 0.45, 0.15, 1.0)),
         make_material((0.0, 0.0, 0.0, 1.0), emissive=(17.0, 12.0, 4.0)),
         make_material((0.9, 0.85, 0.6, 1.0), metallic=1.0, roughness=0.25),
-        make_material((0.6, 0.8, 0.9, 0.4), metallic=0.0, roughness=0.1),
-    ])
+    ] + ([make_material((0.6, 0.8, 0.9, 0.4), metallic=0.0, roughness=0.1)] if glass_pane else []))
     m = _Mesh()
     W, WHITE, RED, GREEN, LIGHT, METAL, GLASS = 1.0, 1, 2, 3, 4, 5, 6
     # room spans [-1,1]^3, open toward +z (camera side)

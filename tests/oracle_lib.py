@@ -27,7 +27,10 @@ def load():
     return _lib
 
 
-def render(lib, packed, rp, threads=8, rows=None, want_ids=True):
+ANYHIT_OPAQUE_SHADOW = 1
+
+
+def render(lib, packed, rp, threads=8, rows=None, want_ids=True, flags=0):
     """orc_render over full image buffers; returns (rgba8, accum, ids, stats dict)."""
     import numpy as np
     from pathtracer_amd import abi
@@ -37,8 +40,8 @@ def render(lib, packed, rp, threads=8, rows=None, want_ids=True):
     ids = np.full((h, w), 0xFFFFFFFF, dtype=np.uint32)
     st = abi.Stats()
     y0, y1 = rows if rows else (0, h)
-    rc = lib.orc_render(C.byref(packed.desc), C.byref(rp), abi.ptr(rgba), abi.ptr(accum),
-                        abi.ptr(ids) if want_ids else None, C.byref(st), C.c_int(threads),
-                        C.c_uint32(y0), C.c_uint32(y1))
+    rc = lib.orc_render_ex(C.byref(packed.desc), C.byref(rp), abi.ptr(rgba), abi.ptr(accum),
+                           abi.ptr(ids) if want_ids else None, C.byref(st), C.c_int(threads),
+                           C.c_uint32(y0), C.c_uint32(y1), C.c_uint32(flags))
     assert rc == 0
     return rgba, accum, ids, st.as_dict()
