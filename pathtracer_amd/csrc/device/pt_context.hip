@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -18,6 +19,9 @@
 namespace {
 
 thread_local std::string g_create_error;
+
+// Slots per band (see render_accum). 0 = no banding. Tunable through PT_BAND_SLOTS for experiments.
+constexpr uint32_t kDefaultBandSlots = 0;
 
 struct DevBuf {
   void* p = nullptr;
@@ -48,6 +52,9 @@ struct pt_ctx {
   uint32_t* rgba8_out = nullptr;
   uint32_t out_pixels = 0;
 
+  uint32_t band_slots = 0;          // 0 = whole frame in one band
+  uint32_t trace_blocks = 0;        // grid cap of the traversal kernels (persistent workgroups striding the queue)
+  uint32_t lds_scene_bytes = 8192;  // LDS per traversal workgroup given to the scene copy (pair records, triangles)
   uint32_t* host_counts = nullptr;  // pinned
   hipEvent_t poll_events[2] = {nullptr, nullptr};
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -231,6 +238,16 @@ extern "C" pt_ctx* pt_create(int device) {
   }
   pt_ctx* ctx = new pt_ctx();
   ctx->device = device;
+  ctx->band_slots = kDefaultBandSlots;
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->trace_blocks = 8u * static_cast<uint32_t>(prop.multiProcessorCount);
+  }
+  if (const char* e = std::getenv("PT_TRACE_BLOCKS")) ctx->trace_blocks = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
+  if (const char* e = std::getenv("PT_LDS_SCENE_BYTES")) ctx->lds_scene_bytes = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
+  if (ctx->trace_blocks == 0) ctx->trace_blocks = 2048;
+  if (ctx->lds_scene_bytes > 32768) ctx->lds_scene_bytes = 32768;
+  if (const char* e = std::getenv("PT_BAND_SLOTS")) ctx->band_slots = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   bool ok = hipSetDevice(device) == hipSuccess &&
             hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
             hipHostMalloc(reinterpret_cast<void**>(&ctx->host_counts), 64, hipHostMallocDefault) == hipSuccess &&
@@ -280,9 +297,40 @@ extern "C" int pt_upload_scene(pt_ctx* ctx, const pt_scene_desc* s) {
   pt_dev_scene d{};
   const size_t ntri = s->triangle_count;
   static_assert(sizeof(pt_packed_bvh_node) == 32 && sizeof(pt_material) == 64, "layout");
-  if ((rc = dev_upload(ctx, ctx->scene_bufs, &d.nodes, reinterpret_cast<const float4*>(s->bvh_nodes),
-                       2 * static_cast<size_t>(s->bvh_node_count))) != PT_OK)
-    return rc;
+  // Child-pair records in breadth-first order: record p of inner node N is
+  // {left.min, left.ref | left.max, left.cnt | right.min, right.ref | right.max, right.cnt},
+  // ref = the child's own record (inner) or its first triangle (leaf). Boxes and triangle
+  // ranges are copied bit for bit from the reference array; only the addressing changes.
+  {
+    const pt_packed_bvh_node* N = s->bvh_nodes;
+    std::vector<uint32_t> order;  // inner nodes, breadth-first
+    std::vector<uint32_t> record_of(s->bvh_node_count, 0xFFFFFFFFu);
+    if (N[0].triangle_count == 0) order.push_back(0);
+    for (size_t head = 0; head < order.size(); ++head) {
+      const uint32_t n = order[head];
+      record_of[n] = static_cast<uint32_t>(head);
+      for (uint32_t side = 0; side < 2; ++side) {
+        const uint32_t c = N[n].left_or_begin + side;
+        if (N[c].triangle_count == 0) order.push_back(c);
+      }
+    }
+    // record_of[] of a child is assigned when the child is dequeued, i.e. after its parent: two passes
+    std::vector<pt_packed_bvh_node> rec(2 * order.size());
+    for (size_t p = 0; p < order.size(); ++p) {
+      for (uint32_t side = 0; side < 2; ++side) {
+        const uint32_t c = N[order[p]].left_or_begin + side;
+        pt_packed_bvh_node r = N[c];
+        if (r.triangle_count == 0) r.left_or_begin = record_of[c];
+        rec[2 * p + side] = r;
+      }
+    }
+    d.pair_count = static_cast<uint32_t>(order.size());
+    d.root_ref = N[0].triangle_count ? N[0].left_or_begin : 0u;
+    d.root_cnt = N[0].triangle_count;
+    if ((rc = dev_upload(ctx, ctx->scene_bufs, &d.pairs, reinterpret_cast<const float4*>(rec.data()), 4 * order.size())) != PT_OK)
+      return rc;
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));  // rec dies here
+  }
   if ((rc = dev_upload(ctx, ctx->scene_bufs, &d.tri_pos, reinterpret_cast<const float4*>(s->vertex_positions), 3 * ntri)) != PT_OK)
     return rc;
 
@@ -360,6 +408,19 @@ extern "C" int pt_upload_scene(pt_ctx* ctx, const pt_scene_desc* s) {
   d.point_light_count = s->point_light_count;
   d.stack_entries = depth + 1;
   d.triangle_count = s->triangle_count;
+  // LDS residency (per traversal workgroup of 256 lanes; the stack takes 1 KiB per level):
+  // a scene whose records + triangles fit in kSmallSceneLds goes in whole; otherwise the
+  // top kTreeletPairs records of the tree.
+  {
+    const size_t whole = 64ull * d.pair_count + 48ull * s->triangle_count;
+    if (whole <= ctx->lds_scene_bytes) {
+      d.lds_pairs = d.pair_count;
+      d.lds_tris = s->triangle_count;
+    } else {
+      d.lds_pairs = d.pair_count < ctx->lds_scene_bytes / 64 ? d.pair_count : ctx->lds_scene_bytes / 64;
+      d.lds_tris = 0;
+    }
+  }
   PT_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
   PT_HIP(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors die here
   float ms = 0.0f;
@@ -409,27 +470,35 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
   const uint32_t tiles_y = (pc.resolution_y + 7) / 8;
   const uint64_t slots64 = static_cast<uint64_t>(f.tiles_x) * tiles_y * 64;
   if (slots64 > 0x7FFFFFFFull) return fail(ctx, PT_ERR_LIMIT, "image too large");
-  f.slot_count = static_cast<uint32_t>(slots64);
+  const uint32_t total_slots = static_cast<uint32_t>(slots64);
   const uint32_t pixels = pc.resolution_x * pc.resolution_y;
 
-  const pt_dev_scene& sc = ctx->scene;
+  // The frame is rendered in BANDS of pixel slots so that the per-slot working set (rays,
+  // hits, path state, shadow requests, queues: ~220 B + 64 B per light per slot) stays
+  // resident in the 256 MiB Infinity Cache instead of streaming through HBM every
+  // iteration; a band is still several waves per SIMD of work (DESIGN.md "Banding").
+  pt_dev_scene sc = ctx->scene;
   const uint32_t n_lights = sc.directional_light_count + sc.point_light_count + (pc.emissive_triangle_count ? 1u : 0u);
-  int rc = ensure_state(ctx, f.slot_count, n_lights, pixels);
+  uint32_t band_slots = ctx->band_slots ? ctx->band_slots : total_slots;
+  band_slots = (band_slots + 63u) & ~63u;
+  if (band_slots > total_slots) band_slots = total_slots;
+  int rc = ensure_state(ctx, band_slots, n_lights, pixels);
   if (rc != PT_OK) return rc;
   const pt_dev_state& st = ctx->state;
   if (!accum_dev) accum_dev = ctx->accum_out;
+  if (!primary_dev) primary_dev = ctx->primary_out;
 
-  // traversal block size: the LDS stack is block * stack_entries words, kept within 64 KiB
-  const uint32_t trace_block = (256u * sc.stack_entries * 4u <= 65536u) ? 256u : 64u;
+  // traversal block size: stack (block * stack_entries words) + the scene copy, kept within 64 KiB
+  const uint32_t trace_block = (256u * sc.stack_entries * 4u + 64u * sc.lds_pairs + 48u * sc.lds_tris <= 65536u) ? 256u : 64u;
+  if (trace_block == 64u && 64u * sc.stack_entries * 4u + 64u * sc.lds_pairs + 48u * sc.lds_tris > 65536u) {
+    sc.lds_tris = 0;  // very deep tree: the stack needs the LDS, the scene copy shrinks to what is left
+    const uint32_t left = 65536u - 64u * sc.stack_entries * 4u;
+    if (64u * sc.lds_pairs > left) sc.lds_pairs = left / 64u;
+  }
   const bool time_kernels = (p->flags & PT_FLAG_TIME_KERNELS) != 0;
   size_t ev_used = 0;
   std::vector<std::pair<size_t, int>> ev_kind;  // index of the start event, kernel id
   uint64_t launches[PT_K_COUNT] = {0, 0, 0, 0};
-
-  PT_HIP(ctx, hipMemsetAsync(st.counters, 0, PT_CNT_WORDS * sizeof(uint32_t), stream));
-  PT_HIP(ctx, hipMemsetAsync(st.stats, 0, static_cast<size_t>(PT_K_COUNT) * st.stat_rows * PT_ST_WORDS * sizeof(unsigned long long), stream));
-  PT_HIP(ctx, hipEventRecord(ctx->ev_start, stream));
-  ptd::launch_init(f, st, stream);
 
   auto timed = [&](int kind, auto&& launch) {
     ++launches[kind];
@@ -447,41 +516,54 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
     launch();
   };
 
+  PT_HIP(ctx, hipMemsetAsync(st.stats, 0, static_cast<size_t>(PT_K_COUNT) * st.stat_rows * PT_ST_WORDS * sizeof(unsigned long long), stream));
+  PT_HIP(ctx, hipEventRecord(ctx->ev_start, stream));
+
   // One path needs at most 8 light steps + 4 pass-through vertices (main.comp:18-19, 512, 542).
   const uint64_t max_iters = static_cast<uint64_t>(f.sample_end - f.sample_begin) * 12ull + 2ull;
   constexpr uint32_t kBatch = 16;
-  uint32_t bound = pixels;  // live entries never increase: the last polled count bounds every later queue
-  uint64_t iter = 0;
-  int poll = 0;
-  bool have_prev = false;
-  bool drained = (f.sample_begin == f.sample_end);
-  while (!drained && iter < max_iters) {
-    for (uint32_t b = 0; b < kBatch; ++b, ++iter) {
-      const uint32_t parity = static_cast<uint32_t>(iter & 1u);
-      timed(PT_K_EXTEND, [&] { ptd::launch_extend(sc, st, parity, bound, trace_block, stream); });
-      timed(PT_K_SHADE, [&] { ptd::launch_shade(sc, f, st, parity, bound, stream); });
-      if (n_lights) timed(PT_K_SHADOW, [&] { ptd::launch_shadow(sc, f, st, bound, trace_block, stream); });
+  uint64_t iter_total = 0;
+  for (uint32_t base = 0; base < total_slots; base += band_slots) {
+    f.slot_base = base;
+    f.slot_count = (total_slots - base < band_slots) ? total_slots - base : band_slots;
+    PT_HIP(ctx, hipMemsetAsync(st.counters, 0, PT_CNT_WORDS * sizeof(uint32_t), stream));
+    ptd::launch_init(f, st, stream);
+
+    uint32_t bound = f.slot_count;  // live entries never increase: the last polled count bounds every later queue
+    uint64_t iter = 0;
+    int poll = 0;
+    bool have_prev = false;
+    bool drained = (f.sample_begin == f.sample_end);
+    while (!drained && iter < max_iters) {
+      for (uint32_t b = 0; b < kBatch; ++b, ++iter) {
+        const uint32_t parity = static_cast<uint32_t>(iter & 1u);
+        timed(PT_K_EXTEND, [&] { ptd::launch_extend(sc, st, parity, bound, trace_block, ctx->trace_blocks, stream); });
+        timed(PT_K_SHADE, [&] { ptd::launch_shade(sc, f, st, parity, bound, stream); });
+        if (n_lights) timed(PT_K_SHADOW, [&] { ptd::launch_shadow(sc, f, st, bound, trace_block, ctx->trace_blocks, stream); });
+      }
+      PT_HIP(ctx, hipGetLastError());
+      // entries queued for the NEXT iteration; stays intact until that iteration's successor recycles it
+      PT_HIP(ctx, hipMemcpyAsync(&ctx->host_counts[poll], st.counters + PT_CNT_QUEUE0 + (iter & 1u), sizeof(uint32_t),
+                                 hipMemcpyDeviceToHost, stream));
+      PT_HIP(ctx, hipEventRecord(ctx->poll_events[poll], stream));
+      if (have_prev) {  // look at the previous batch while this one runs: the GPU never waits for the host
+        PT_HIP(ctx, hipEventSynchronize(ctx->poll_events[poll ^ 1]));
+        const uint32_t live = ctx->host_counts[poll ^ 1];
+        if (live == 0) drained = true;
+        else if (live < bound) bound = live;
+      }
+      have_prev = true;
+      poll ^= 1;
     }
-    PT_HIP(ctx, hipGetLastError());
-    // entries queued for the NEXT iteration; stays intact until that iteration's successor recycles it
-    PT_HIP(ctx, hipMemcpyAsync(&ctx->host_counts[poll], st.counters + PT_CNT_QUEUE0 + (iter & 1u), sizeof(uint32_t),
-                               hipMemcpyDeviceToHost, stream));
-    PT_HIP(ctx, hipEventRecord(ctx->poll_events[poll], stream));
-    if (have_prev) {  // look at the previous batch while this one runs: the GPU never waits for the host
+    if (!drained) {
       PT_HIP(ctx, hipEventSynchronize(ctx->poll_events[poll ^ 1]));
-      const uint32_t live = ctx->host_counts[poll ^ 1];
-      if (live == 0) drained = true;
-      else if (live < bound) bound = live;
+      if (ctx->host_counts[poll ^ 1] != 0)
+        return fail(ctx, PT_ERR_DEVICE, "wavefront loop did not drain after %llu iterations", static_cast<unsigned long long>(iter));
     }
-    have_prev = true;
-    poll ^= 1;
+    ptd::launch_finalize(f, st, accum_dev, primary_dev, stream);
+    iter_total += iter;
   }
-  if (!drained) {
-    PT_HIP(ctx, hipEventSynchronize(ctx->poll_events[poll ^ 1]));
-    if (ctx->host_counts[poll ^ 1] != 0)
-      return fail(ctx, PT_ERR_DEVICE, "wavefront loop did not drain after %llu iterations", static_cast<unsigned long long>(iter));
-  }
-  ptd::launch_finalize(f, st, accum_dev, primary_dev ? primary_dev : ctx->primary_out, stream);
+  const uint64_t iter = iter_total;
   PT_HIP(ctx, hipEventRecord(ctx->ev_stop, stream));
   PT_HIP(ctx, hipGetLastError());
   PT_HIP(ctx, hipStreamSynchronize(stream));

@@ -15,15 +15,19 @@ enum { PT_ST_PATHS = 0, PT_ST_RAYS, PT_ST_VISITS, PT_ST_TESTS, PT_ST_HITS, PT_ST
 enum { PT_K_INIT = 0, PT_K_EXTEND, PT_K_SHADE, PT_K_SHADOW, PT_K_COUNT };
 
 // The scene in HBM, split by who reads it:
-//   nodes      traversal only   — the reference's 32-byte PackedBVHNode array verbatim; a
-//                                  sibling pair {2k,2k+1} is one aligned 64-byte record
+//   pairs      traversal only   — one 64-byte record per INNER node holding both children
+//                                  {min, ref | max, count} x 2, breadth-first order (derived
+//                                  at upload from the reference's PackedBVHNode array; the
+//                                  boxes and triangle ranges are copied bit for bit); the
+//                                  first lds_pairs records are staged in LDS by every
+//                                  traversal workgroup
 //   tri_pos    traversal + shade — the reference's binding 0 verbatim: 3 x vec4 per triangle
 //   tri_attr   shade only        — 64 bytes per triangle: 3 normals, 3 uvs, material index
 //                                  (the reference's 192-byte vertex triple minus the
 //                                  tangent / bitangent / duplicate position it never reads, Q15)
 //   materials  shade             — the reference's 64-byte Material array verbatim
 struct pt_dev_scene {
-  const float4* nodes;
+  const float4* pairs;
   const float4* tri_pos;
   const float4* tri_attr;
   const float4* materials;
@@ -36,6 +40,9 @@ struct pt_dev_scene {
   uint32_t point_light_count;
   uint32_t stack_entries;            // LDS stack rows per lane (bvh_max_depth + 1)
   uint32_t triangle_count;
+  uint32_t pair_count;
+  uint32_t root_ref, root_cnt;       // the root as a child reference: pair 0 (count 0) or a leaf's triangle range
+  uint32_t lds_pairs, lds_tris;      // how much of pairs / tri_pos each traversal workgroup stages in LDS
   uint32_t all_opaque;               // 1: no surface can report alpha != 1 (shadow rays may stop at the first hit)
 };
 
@@ -46,7 +53,8 @@ struct pt_dev_frame {
   uint32_t sample_begin;   // strata [begin, end) rendered by this rank
   uint32_t sample_end;
   uint32_t rank, num_ranks;
-  uint32_t slot_count;     // tiles_x * tiles_y * 64
+  uint32_t slot_base;      // first slot of the band being rendered (slots are 8x8-pixel tiles, row-major)
+  uint32_t slot_count;     // slots in this band (a multiple of 64)
   uint32_t tiles_x;
 };
 
@@ -71,11 +79,11 @@ struct pt_dev_state {
 namespace ptd {
 void launch_init(const pt_dev_frame& f, const pt_dev_state& st, hipStream_t s);
 void launch_extend(const pt_dev_scene& sc, const pt_dev_state& st, uint32_t parity, uint32_t max_entries, uint32_t block,
-                   hipStream_t s);
+                   uint32_t max_blocks, hipStream_t s);
 void launch_shade(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity,
                   uint32_t max_entries, hipStream_t s);
 void launch_shadow(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t max_entries,
-                   uint32_t block, hipStream_t s);
+                   uint32_t block, uint32_t max_blocks, hipStream_t s);
 void launch_finalize(const pt_dev_frame& f, const pt_dev_state& st, float4* accum_out, uint32_t* primary_out, hipStream_t s);
 void launch_resolve(const float4* accum, uint32_t pixel_count, uint32_t* rgba8, hipStream_t s);
 }  // namespace ptd

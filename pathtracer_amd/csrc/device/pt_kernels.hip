@@ -146,15 +146,48 @@ struct Hit {
   uint32_t tri;
 };
 
-// ray_triangle_intersect, main.comp:189-217. Positions are the reference's binding 0:
-// three vec4 per triangle (48 B, one aligned 16-B load per vertex).
-__device__ __forceinline__ void ray_triangle(const float4* __restrict__ tri_pos, vec3 o, vec3 d, uint32_t tri, Hit& h) {
-  const float4 q0 = tri_pos[3 * static_cast<size_t>(tri)];
-  const float4 q1 = tri_pos[3 * static_cast<size_t>(tri) + 1];
-  const float4 q2 = tri_pos[3 * static_cast<size_t>(tri) + 2];
-  const vec3 p0 = xyz(q0);
-  const vec3 edge1 = xyz(q1) - p0;
-  const vec3 edge2 = xyz(q2) - p0;
+// ray_aabb_intersect, main.comp:169-185, with inv_dir hoisted out of the loop (bit-identical)
+__device__ __forceinline__ bool ray_box(vec3 o, vec3 inv, const float4& bmin, const float4& bmax, float& t_near) {
+  const vec3 t_min = inv * (xyz(bmin) - o);
+  const vec3 t_max = inv * (xyz(bmax) - o);
+  const float n = gmax(gmax(gmin(t_min.x, t_max.x), gmin(t_min.y, t_max.y)), gmin(t_min.z, t_max.z));
+  const float f = gmin(gmin(gmax(t_min.x, t_max.x), gmax(t_min.y, t_max.y)), gmax(t_min.z, t_max.z));
+  t_near = n;
+  return n <= f;
+}
+
+// Where a traversal reads the scene from. The BVH is held as CHILD-PAIR records in
+// breadth-first order (built at upload from the reference's node array, pt_context.hip):
+// record p = {left.min, left.ref | left.max, left.cnt | right.min, right.ref | right.max,
+// right.cnt}, 64 bytes, where ref is the child's own pair record (inner) or its first
+// triangle (leaf). The first `lds_pairs` records — the top of the tree, which every ray
+// walks — and, for small scenes, the triangle positions are staged in LDS by each
+// workgroup: divergent 16-byte lane loads cost one L1 tag look-up per lane (the vector
+// memory pipe, not the VALU, bounded the first version of this kernel), while ds_read_b128
+// serves 64 lanes in a few cycles. Deeper records come from global memory.
+struct Tracer {
+  const float4* __restrict__ pairs;    // global, breadth-first
+  const float4* __restrict__ tri_pos;  // global, 3 x float4 per triangle
+  const float4* lds_pair;              // LDS copy of records [0, lds_pairs)
+  const float4* lds_tri;               // LDS copy of triangles [0, lds_tris)
+  uint32_t lds_pairs, lds_tris;
+  uint32_t root_ref, root_cnt;
+  uint32_t* stack;                     // this lane's column of the LDS stack
+  uint32_t stride;
+};
+
+__device__ __forceinline__ float4 pair_word(const Tracer& tr, uint32_t pair, uint32_t w) {
+  return pair < tr.lds_pairs ? tr.lds_pair[4 * pair + w] : tr.pairs[4 * static_cast<size_t>(pair) + w];
+}
+__device__ __forceinline__ float4 tri_word(const Tracer& tr, uint32_t tri, uint32_t w) {
+  return tri < tr.lds_tris ? tr.lds_tri[3 * tri + w] : tr.tri_pos[3 * static_cast<size_t>(tri) + w];
+}
+
+// ray_triangle_intersect, main.comp:189-217
+__device__ __forceinline__ void ray_triangle(const Tracer& tr, vec3 o, vec3 d, uint32_t tri, Hit& h) {
+  const vec3 p0 = xyz(tri_word(tr, tri, 0));
+  const vec3 edge1 = xyz(tri_word(tr, tri, 1)) - p0;
+  const vec3 edge2 = xyz(tri_word(tr, tri, 2)) - p0;
   const vec3 ray_cross_edge2 = cross(d, edge2);
   const float det = dot(edge1, ray_cross_edge2);
   if (__builtin_fabsf(det) < kEpsilon) return;
@@ -177,49 +210,38 @@ __device__ __forceinline__ void ray_triangle(const float4* __restrict__ tri_pos,
   }
 }
 
-// ray_aabb_intersect, main.comp:169-185, with inv_dir hoisted out of the loop (bit-identical)
-__device__ __forceinline__ bool ray_box(vec3 o, vec3 inv, const float4& bmin, const float4& bmax, float& t_near) {
-  const vec3 t_min = inv * (xyz(bmin) - o);
-  const vec3 t_max = inv * (xyz(bmax) - o);
-  const float n = gmax(gmax(gmin(t_min.x, t_max.x), gmin(t_min.y, t_max.y)), gmin(t_min.z, t_max.z));
-  const float f = gmin(gmin(gmax(t_min.x, t_max.x), gmax(t_min.y, t_max.y)), gmax(t_min.z, t_max.z));
-  t_near = n;
-  return n <= f;
-}
-
 // ray_scene_intersect, main.comp:263-304. Same visiting order as the reference (near child
 // first, far child deferred, leaf triangles in index order, no re-cull on pop): when both
 // children are hit the near one is entered directly instead of being pushed and popped.
 // The deferred far children live in an LDS stack, one column per lane
-// (stack[level * stride + lane]: conflict-free ds_read/ds_write_b32).
-// A sibling pair {2k, 2k+1} is one aligned 64-byte record (4 x float4).
+// (stack[level * stride + lane]: conflict-free ds_read/ds_write_b32); an entry names a
+// child as (pair record << 1 | side).
 // ANY_HIT (shadow rays of provably all-opaque scenes): the traversal ends at the first
 // accepted triangle. The order is unchanged, so whether a hit exists is decided exactly as
 // by the full closest-hit search; h then holds *a* hit, not the closest.
 template <bool ANY_HIT>
-__device__ __forceinline__ void traverse(const float4* __restrict__ nodes, const float4* __restrict__ tri_pos,
-                                         vec3 o, vec3 d, Hit& h, uint32_t* stack, uint32_t stride, Tally& tally) {
+__device__ __forceinline__ void traverse(const Tracer& tr, vec3 o, vec3 d, Hit& h, Tally& tally) {
   ++tally.rays;
   const vec3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
   uint32_t sp = 0;
-  uint32_t lob = fbits(nodes[0].w);  // root: never box-tested (Q13)
-  uint32_t cnt = fbits(nodes[1].w);
+  uint32_t ref = tr.root_ref;  // root: never box-tested (Q13)
+  uint32_t cnt = tr.root_cnt;
   for (;;) {
     if (cnt > 0) {
       if (ANY_HIT) {
         for (uint32_t i = 0; i < cnt; ++i) {
           ++tally.tests;
-          ray_triangle(tri_pos, o, d, lob + i, h);
+          ray_triangle(tr, o, d, ref + i, h);
           if (h.tri != kNoHit) return;
         }
       } else {
         tally.tests += cnt;
-        for (uint32_t i = 0; i < cnt; ++i) ray_triangle(tri_pos, o, d, lob + i, h);
+        for (uint32_t i = 0; i < cnt; ++i) ray_triangle(tr, o, d, ref + i, h);
       }
     } else {
       ++tally.visits;
-      const float4* pair = nodes + 2 * static_cast<size_t>(lob);
-      const float4 l0 = pair[0], l1 = pair[1], r0 = pair[2], r1 = pair[3];
+      const float4 l0 = pair_word(tr, ref, 0), l1 = pair_word(tr, ref, 1);
+      const float4 r0 = pair_word(tr, ref, 2), r1 = pair_word(tr, ref, 3);
       float dist_l, dist_r;
       bool hit_l = ray_box(o, inv, l0, l1, dist_l);
       bool hit_r = ray_box(o, inv, r0, r1, dist_r);
@@ -228,26 +250,43 @@ __device__ __forceinline__ void traverse(const float4* __restrict__ nodes, const
       if (hit_l || hit_r) {
         const bool go_left = hit_l && (!hit_r || dist_l < dist_r);  // equal distances: right is near (Q14)
         if (hit_l && hit_r) {
-          stack[sp * stride] = go_left ? lob + 1 : lob;
+          tr.stack[sp * tr.stride] = (ref << 1) | (go_left ? 1u : 0u);  // the far side
           ++sp;
         }
-        const uint32_t nl = go_left ? fbits(l0.w) : fbits(r0.w);
+        ref = go_left ? fbits(l0.w) : fbits(r0.w);
         cnt = go_left ? fbits(l1.w) : fbits(r1.w);
-        lob = nl;
         continue;
       }
     }
     if (sp == 0) break;
     --sp;
-    const uint32_t idx = stack[sp * stride];
-    lob = fbits(nodes[2 * static_cast<size_t>(idx)].w);
-    cnt = fbits(nodes[2 * static_cast<size_t>(idx) + 1].w);
+    const uint32_t e = tr.stack[sp * tr.stride];
+    const uint32_t pair = e >> 1, side = 2u * (e & 1u);
+    ref = fbits(pair_word(tr, pair, side).w);
+    cnt = fbits(pair_word(tr, pair, side + 1u).w);
   }
 }
 
-__device__ __forceinline__ void closest_hit(const float4* __restrict__ nodes, const float4* __restrict__ tri_pos,
-                                            vec3 o, vec3 d, Hit& h, uint32_t* stack, uint32_t stride, Tally& tally) {
-  traverse<false>(nodes, tri_pos, o, d, h, stack, stride, tally);
+// Workgroup prologue of the traversal kernels: carve the dynamic LDS into
+// [stack | pair records | triangles] and stage the LDS-resident part of the scene.
+__device__ __forceinline__ Tracer make_tracer(const pt_dev_scene& sc, uint32_t* lds) {
+  float4* lds_pair = reinterpret_cast<float4*>(lds + static_cast<size_t>(blockDim.x) * sc.stack_entries);
+  float4* lds_tri = lds_pair + 4 * static_cast<size_t>(sc.lds_pairs);
+  for (uint32_t i = threadIdx.x; i < 4u * sc.lds_pairs; i += blockDim.x) lds_pair[i] = sc.pairs[i];
+  for (uint32_t i = threadIdx.x; i < 3u * sc.lds_tris; i += blockDim.x) lds_tri[i] = sc.tri_pos[i];
+  __syncthreads();
+  Tracer tr;
+  tr.pairs = sc.pairs;
+  tr.tri_pos = sc.tri_pos;
+  tr.lds_pair = lds_pair;
+  tr.lds_tri = lds_tri;
+  tr.lds_pairs = sc.lds_pairs;
+  tr.lds_tris = sc.lds_tris;
+  tr.root_ref = sc.root_ref;
+  tr.root_cnt = sc.root_cnt;
+  tr.stack = lds + threadIdx.x;
+  tr.stride = blockDim.x;
+  return tr;
 }
 
 // ---------------------------------------------------------------- scene fetch
@@ -467,7 +506,9 @@ __device__ __forceinline__ void finish_sample(vec3 color, vec3 indirect, vec3 bg
 }
 
 // slot <-> pixel: slots are 8x8 pixel tiles (64 consecutive slots = one wave = one tile)
-__device__ __forceinline__ bool slot_to_pixel(const pt_dev_frame& f, uint32_t slot, uint32_t& x, uint32_t& y) {
+// (a slot index is local to the band being rendered; f.slot_base is the band's first slot)
+__device__ __forceinline__ bool slot_to_pixel(const pt_dev_frame& f, uint32_t local_slot, uint32_t& x, uint32_t& y) {
+  const uint32_t slot = local_slot + f.slot_base;
   const uint32_t tile = slot >> 6, in = slot & 63u;
   const uint32_t ty = tile / f.tiles_x, tx = tile - ty * f.tiles_x;
   x = tx * 8u + (in & 7u);
@@ -523,22 +564,26 @@ __global__ __launch_bounds__(256) void k_init(pt_dev_frame f, pt_dev_state st) {
   flush_tally(tally, st, PT_K_INIT);
 }
 
-// Closest hit for every queued ray.
+// Closest hit for every queued ray. Persistent workgroups: the grid is a few blocks per CU
+// and each block walks the queue in strides, so the LDS scene copy is staged once per
+// block, not once per 256 rays.
 __global__ __launch_bounds__(256) void k_extend(pt_dev_scene sc, pt_dev_state st, uint32_t parity) {
-  extern __shared__ uint32_t lds_stack[];
-  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
   const uint32_t n = st.counters[PT_CNT_QUEUE0 + parity];
-  if (gid == 0) {  // recycle the counters the previous iteration consumed
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // recycle the counters the previous iteration consumed
     st.counters[PT_CNT_QUEUE0 + (parity ^ 1u)] = 0;
     st.counters[PT_CNT_SHADOW] = 0;
   }
   Tally tally;
-  if (gid < n) {
-    const uint32_t slot = st.queue[parity][gid];
-    const float4 o4 = st.ray_o[slot], d4 = st.ray_d[slot];
-    Hit h{kInfinity, 0.0f, 0.0f, kNoHit};
-    closest_hit(sc.nodes, sc.tri_pos, xyz(o4), xyz(d4), h, lds_stack + threadIdx.x, blockDim.x, tally);
-    st.hit[slot] = make_uint4(h.tri, fbits(h.u), fbits(h.v), fbits(h.t));
+  if (blockIdx.x * blockDim.x < n) {  // block-uniform
+    const Tracer tr = make_tracer(sc, lds_dyn);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+      const uint32_t slot = st.queue[parity][i];
+      const float4 o4 = st.ray_o[slot], d4 = st.ray_d[slot];
+      Hit h{kInfinity, 0.0f, 0.0f, kNoHit};
+      traverse<false>(tr, xyz(o4), xyz(d4), h, tally);
+      st.hit[slot] = make_uint4(h.tri, fbits(h.u), fbits(h.v), fbits(h.t));
+    }
   }
   flush_tally(tally, st, PT_K_EXTEND);
 }
@@ -765,19 +810,19 @@ __global__ __launch_bounds__(256) void k_shade(pt_dev_scene sc, pt_dev_frame f, 
 
 // ray_scene_intersect_with_transparency, main.comp:306-332. Returns the transparency and
 // leaves the last traversal's result in h.
-__device__ __forceinline__ float shadow_walk(const pt_dev_scene& sc, vec3 origin, vec3 dir, Hit& h, uint32_t* stack,
-                                             uint32_t stride, Tally& tally) {
+__device__ __forceinline__ float shadow_walk(const pt_dev_scene& sc, const Tracer& tr, vec3 origin, vec3 dir, Hit& h,
+                                             Tally& tally) {
   float transparency = 1.0f;
   if (sc.all_opaque) {  // every closest hit has alpha == 1 and returns 0 (main.comp:325): any hit decides
     h.t = kInfinity;
     h.tri = kNoHit;
-    traverse<true>(sc.nodes, sc.tri_pos, origin, dir, h, stack, stride, tally);
+    traverse<true>(tr, origin, dir, h, tally);
     return h.tri == kNoHit ? 1.0f : 0.0f;
   }
   for (uint32_t step = 0; step < kMaxTransparencySteps; ++step) {
     h.t = kInfinity;
     h.tri = kNoHit;
-    closest_hit(sc.nodes, sc.tri_pos, origin, dir, h, stack, stride, tally);
+    traverse<false>(tr, origin, dir, h, tally);
     if (h.tri == kNoHit) break;
     const vec3 wuv = mk(1.0f - h.u - h.v, h.u, h.v);
     vec3 pos;
@@ -797,11 +842,12 @@ __device__ __forceinline__ float shadow_walk(const pt_dev_scene& sc, vec3 origin
 // Shadow walks of one path vertex + the direct-lighting accumulate; finishes the sample
 // when the vertex was the path's last (light step 8).
 __global__ __launch_bounds__(256) void k_shadow(pt_dev_scene sc, pt_dev_frame f, pt_dev_state st) {
-  extern __shared__ uint32_t lds_stack[];
-  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
   const uint32_t n = st.counters[PT_CNT_SHADOW];
   Tally tally;
-  if (gid < n) {
+  if (blockIdx.x * blockDim.x < n) {  // block-uniform
+  const Tracer tr = make_tracer(sc, lds_dyn);
+  for (uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x; gid < n; gid += gridDim.x * blockDim.x) {
     const uint32_t slot = st.shadow_queue[gid];
     const float4* hdr = st.shadow_hdr + 4 * static_cast<size_t>(slot);
     const float4 h0 = hdr[0], h1 = hdr[1], h3 = hdr[3];
@@ -809,14 +855,13 @@ __global__ __launch_bounds__(256) void k_shadow(pt_dev_scene sc, pt_dev_frame f,
     const uint32_t n_punctual = sc.directional_light_count + sc.point_light_count;
     const uint32_t n_lights = n_punctual + (f.pc.emissive_triangle_count ? 1u : 0u);
     const float4* rec = st.shadow_rec + 4 * static_cast<size_t>(slot) * n_lights;
-    uint32_t* stack = lds_stack + threadIdx.x;
 
     vec3 punctual = splat(0.0f);  // sample_punctual_light's `color`, main.comp:410
     vec3 area = splat(0.0f);
     for (uint32_t k = 0; k < n_lights; ++k, rec += 4) {
       const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
       Hit h{kInfinity, 0.0f, 0.0f, kNoHit};
-      const float transparency = shadow_walk(sc, origin, xyz(r0), h, stack, blockDim.x, tally);
+      const float transparency = shadow_walk(sc, tr, origin, xyz(r0), h, tally);
       if (transparency == 0.0f) continue;                                   // :423 / :446 / :486
       if (h.tri != kNoHit && h.t + r1.w < r0.w) continue;                   // :448 / :488
       vec3 radiance = xyz(r1);
@@ -843,6 +888,7 @@ __global__ __launch_bounds__(256) void k_shadow(pt_dev_scene sc, pt_dev_frame f,
       color = splat(0.0f);
     }
     st.path_b[slot] = make_float4(color.x, color.y, color.z, pb.w);
+  }
   }
   flush_tally(tally, st, PT_K_SHADOW);
 }
@@ -886,10 +932,15 @@ void launch_init(const pt_dev_frame& f, const pt_dev_state& st, hipStream_t s) {
   hipLaunchKernelGGL(k_init, dim3(blocks_for(f.slot_count, 256)), dim3(256), 0, s, f, st);
 }
 
+static inline size_t trace_lds_bytes(const pt_dev_scene& sc, uint32_t block) {
+  return static_cast<size_t>(block) * sc.stack_entries * sizeof(uint32_t) + 64u * sc.lds_pairs + 48u * sc.lds_tris;
+}
+
 void launch_extend(const pt_dev_scene& sc, const pt_dev_state& st, uint32_t parity, uint32_t max_entries, uint32_t block,
-                   hipStream_t s) {
-  const size_t lds = static_cast<size_t>(block) * sc.stack_entries * sizeof(uint32_t);
-  hipLaunchKernelGGL(k_extend, dim3(blocks_for(max_entries, block)), dim3(block), lds, s, sc, st, parity);
+                   uint32_t max_blocks, hipStream_t s) {
+  uint32_t grid = blocks_for(max_entries, block);
+  if (grid > max_blocks) grid = max_blocks;
+  hipLaunchKernelGGL(k_extend, dim3(grid), dim3(block), trace_lds_bytes(sc, block), s, sc, st, parity);
 }
 
 void launch_shade(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity,
@@ -898,9 +949,10 @@ void launch_shade(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_st
 }
 
 void launch_shadow(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t max_entries,
-                   uint32_t block, hipStream_t s) {
-  const size_t lds = static_cast<size_t>(block) * sc.stack_entries * sizeof(uint32_t);
-  hipLaunchKernelGGL(k_shadow, dim3(blocks_for(max_entries, block)), dim3(block), lds, s, sc, f, st);
+                   uint32_t block, uint32_t max_blocks, hipStream_t s) {
+  uint32_t grid = blocks_for(max_entries, block);
+  if (grid > max_blocks) grid = max_blocks;
+  hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(block), trace_lds_bytes(sc, block), s, sc, f, st);
 }
 
 void launch_finalize(const pt_dev_frame& f, const pt_dev_state& st, float4* accum_out, uint32_t* primary_out, hipStream_t s) {
