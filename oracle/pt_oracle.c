@@ -372,6 +372,7 @@ typedef struct {
   uint32_t rand_state;
   uint32_t* stack;
   int any_hit_shadows; /* ORC_FLAG_ANYHIT_OPAQUE_SHADOW and the scene is provably all-opaque */
+  int cull_behind;     /* ORC_FLAG_CULL_BEHIND: skip boxes with t_far < 0 (checker mirror of the HIP path) */
   pt_stats st;
 } shctx;
 
@@ -417,7 +418,7 @@ static v3 sample_triangle(shctx* c) {
 }
 
 /* main.comp:169-185 */
-static int ray_aabb_intersect(const ray_t* ray, const float* bmin, const float* bmax, float* t) {
+static int ray_aabb_intersect(const ray_t* ray, const float* bmin, const float* bmax, float* t, int cull_behind) {
   v3 inv_dir = V(1.0f / ray->dir.x, 1.0f / ray->dir.y, 1.0f / ray->dir.z);
   v3 t_min = vmul(inv_dir, vsub(v3from(bmin), ray->origin));
   v3 t_max = vmul(inv_dir, vsub(v3from(bmax), ray->origin));
@@ -426,6 +427,7 @@ static int ray_aabb_intersect(const ray_t* ray, const float* bmin, const float* 
   float t_near = gmax(gmax(t1.x, t1.y), t1.z);
   float t_far = gmin(gmin(t2.x, t2.y), t2.z);
   *t = t_near;
+  if (cull_behind && t_far < 0.0f) return 0; /* not in the reference: see ORC_FLAG_CULL_BEHIND */
   return t_near <= t_far;
 }
 
@@ -572,8 +574,8 @@ static void ray_scene_intersect_ex(shctx* c, const ray_t* ray, isect_t* info, in
       const pt_packed_bvh_node* left = &nodes[node->left_or_begin];
       const pt_packed_bvh_node* right = &nodes[node->left_or_begin + 1];
       float dist_left, dist_right;
-      int li = ray_aabb_intersect(ray, left->aabb_min, left->aabb_max, &dist_left);
-      int ri = ray_aabb_intersect(ray, right->aabb_min, right->aabb_max, &dist_right);
+      int li = ray_aabb_intersect(ray, left->aabb_min, left->aabb_max, &dist_left, c->cull_behind);
+      int ri = ray_aabb_intersect(ray, right->aabb_min, right->aabb_max, &dist_right, c->cull_behind);
       li = li && (dist_left < info->t);
       ri = ri && (dist_right < info->t);
       if (li && ri) {
@@ -963,6 +965,7 @@ typedef struct {
   uint32_t y_begin, y_end;
   volatile uint32_t* next_row;
   int any_hit_shadows;
+  int cull_behind;
   pt_stats st;
 } worker_arg;
 
@@ -973,6 +976,7 @@ static void* worker_main(void* p) {
   c.sc = w->sc;
   c.pc = &w->rp->pc;
   c.any_hit_shadows = w->any_hit_shadows;
+  c.cull_behind = w->cull_behind;
   c.stack = (uint32_t*)malloc(sizeof(uint32_t) * (w->sc->bvh_max_depth + 64)); /* main.comp:263-265 */
   for (;;) {
     uint32_t y = __sync_fetch_and_add(w->next_row, 1u);
@@ -1027,6 +1031,7 @@ int orc_render_ex(const pt_scene_desc* scene, const pt_render_params* params, ui
     w->sc = scene; w->rp = params; w->rgba8 = rgba8_out; w->accum = accum_out;
     w->primary_id = primary_id_out; w->y_begin = y_begin; w->y_end = y_end; w->next_row = &next_row;
     w->any_hit_shadows = any_hit;
+    w->cull_behind = (flags & ORC_FLAG_CULL_BEHIND) != 0;
     if (num_threads > 1) pthread_create(&th[i], NULL, worker_main, w);
     else worker_main(w);
   }

@@ -40,6 +40,10 @@ int orc_render(const pt_scene_desc* scene, const pt_render_params* params, uint8
  * images are identical to orc_render by construction, only node_visits / tri_tests /
  * hits_shaded differ; it exists so the GPU work counters can be checked for equality. */
 #define ORC_FLAG_ANYHIT_OPAQUE_SHADOW 1u
+/* ORC_FLAG_CULL_BEHIND mirrors the HIP path's extra box cull (t_far < 0: the box lies behind
+ * the ray origin): no triangle in such a box can pass `t > epsilon`, so images
+ * are identical (tests/test_oracle_shader.py checks it); visits/tests shrink. */
+#define ORC_FLAG_CULL_BEHIND 2u
 int orc_render_ex(const pt_scene_desc* scene, const pt_render_params* params, uint8_t* rgba8_out,
                   float* accum_out, uint32_t* primary_id_out, pt_stats* stats_out, int num_threads,
                   uint32_t y_begin, uint32_t y_end, uint32_t flags);

@@ -54,7 +54,7 @@ struct pt_ctx {
 
   uint32_t band_slots = 0;          // 0 = whole frame in one band
   uint32_t trace_blocks = 0;        // grid cap of the traversal kernels (persistent workgroups striding the queue)
-  uint32_t lds_scene_bytes = 8192;  // LDS per traversal workgroup given to the scene copy (pair records, triangles)
+  uint32_t lds_scene_bytes = 12288; // scenes up to this size (pair records + triangle positions) are staged whole in LDS
   uint32_t* host_counts = nullptr;  // pinned
   hipEvent_t poll_events[2] = {nullptr, nullptr};
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -408,19 +408,9 @@ extern "C" int pt_upload_scene(pt_ctx* ctx, const pt_scene_desc* s) {
   d.point_light_count = s->point_light_count;
   d.stack_entries = depth + 1;
   d.triangle_count = s->triangle_count;
-  // LDS residency (per traversal workgroup of 256 lanes; the stack takes 1 KiB per level):
-  // a scene whose records + triangles fit in kSmallSceneLds goes in whole; otherwise the
-  // top kTreeletPairs records of the tree.
-  {
-    const size_t whole = 64ull * d.pair_count + 48ull * s->triangle_count;
-    if (whole <= ctx->lds_scene_bytes) {
-      d.lds_pairs = d.pair_count;
-      d.lds_tris = s->triangle_count;
-    } else {
-      d.lds_pairs = d.pair_count < ctx->lds_scene_bytes / 64 ? d.pair_count : ctx->lds_scene_bytes / 64;
-      d.lds_tris = 0;
-    }
-  }
+  // LDS residency: a scene whose pair records + triangle positions fit in lds_scene_bytes
+  // is staged whole in every traversal workgroup's LDS (next to the 1 KiB-per-level stack).
+  d.scene_in_lds = (64ull * d.pair_count + 48ull * s->triangle_count <= ctx->lds_scene_bytes) ? 1u : 0u;
   PT_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
   PT_HIP(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors die here
   float ms = 0.0f;
@@ -489,12 +479,9 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
   if (!primary_dev) primary_dev = ctx->primary_out;
 
   // traversal block size: stack (block * stack_entries words) + the scene copy, kept within 64 KiB
-  const uint32_t trace_block = (256u * sc.stack_entries * 4u + 64u * sc.lds_pairs + 48u * sc.lds_tris <= 65536u) ? 256u : 64u;
-  if (trace_block == 64u && 64u * sc.stack_entries * 4u + 64u * sc.lds_pairs + 48u * sc.lds_tris > 65536u) {
-    sc.lds_tris = 0;  // very deep tree: the stack needs the LDS, the scene copy shrinks to what is left
-    const uint32_t left = 65536u - 64u * sc.stack_entries * 4u;
-    if (64u * sc.lds_pairs > left) sc.lds_pairs = left / 64u;
-  }
+  const uint32_t scene_lds = sc.scene_in_lds ? 64u * sc.pair_count + 48u * sc.triangle_count : 0u;
+  if (256u * sc.stack_entries * 4u + scene_lds > 65536u) sc.scene_in_lds = 0;  // deep tree: the stack needs the LDS
+  const uint32_t trace_block = (256u * sc.stack_entries * 4u <= 65536u) ? 256u : 64u;
   const bool time_kernels = (p->flags & PT_FLAG_TIME_KERNELS) != 0;
   size_t ev_used = 0;
   std::vector<std::pair<size_t, int>> ev_kind;  // index of the start event, kernel id

@@ -18,9 +18,8 @@ enum { PT_K_INIT = 0, PT_K_EXTEND, PT_K_SHADE, PT_K_SHADOW, PT_K_COUNT };
 //   pairs      traversal only   — one 64-byte record per INNER node holding both children
 //                                  {min, ref | max, count} x 2, breadth-first order (derived
 //                                  at upload from the reference's PackedBVHNode array; the
-//                                  boxes and triangle ranges are copied bit for bit); the
-//                                  first lds_pairs records are staged in LDS by every
-//                                  traversal workgroup
+//                                  boxes and triangle ranges are copied bit for bit); small
+//                                  scenes are staged whole in LDS by every traversal workgroup
 //   tri_pos    traversal + shade — the reference's binding 0 verbatim: 3 x vec4 per triangle
 //   tri_attr   shade only        — 64 bytes per triangle: 3 normals, 3 uvs, material index
 //                                  (the reference's 192-byte vertex triple minus the
@@ -42,7 +41,7 @@ struct pt_dev_scene {
   uint32_t triangle_count;
   uint32_t pair_count;
   uint32_t root_ref, root_cnt;       // the root as a child reference: pair 0 (count 0) or a leaf's triangle range
-  uint32_t lds_pairs, lds_tris;      // how much of pairs / tri_pos each traversal workgroup stages in LDS
+  uint32_t scene_in_lds;             // 1: pair records + triangle positions are staged whole in every traversal workgroup's LDS
   uint32_t all_opaque;               // 1: no surface can report alpha != 1 (shadow rays may stop at the first hit)
 };
 

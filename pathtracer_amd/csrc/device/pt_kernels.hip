@@ -146,48 +146,70 @@ struct Hit {
   uint32_t tri;
 };
 
-// ray_aabb_intersect, main.comp:169-185, with inv_dir hoisted out of the loop (bit-identical)
-__device__ __forceinline__ bool ray_box(vec3 o, vec3 inv, const float4& bmin, const float4& bmax, float& t_near) {
-  const vec3 t_min = inv * (xyz(bmin) - o);
-  const vec3 t_max = inv * (xyz(bmax) - o);
-  const float n = gmax(gmax(gmin(t_min.x, t_max.x), gmin(t_min.y, t_max.y)), gmin(t_min.z, t_max.z));
-  const float f = gmin(gmin(gmax(t_min.x, t_max.x), gmax(t_min.y, t_max.y)), gmax(t_min.z, t_max.z));
-  t_near = n;
-  return n <= f;
+// ray_aabb_intersect, main.comp:169-185, for BOTH children of a pair at once. inv_dir is
+// hoisted out of the loop (bit-identical), and the x/y/z slab arithmetic of the left and
+// right box runs in the two halves of packed fp32 instructions (v_pk_add_f32 /
+// v_pk_mul_f32: a wave64 VALU op costs 4 cycles on a SIMD, packed or not, and this kernel
+// is VALU-issue bound). Component-wise IEEE sub/mul, so the values equal the scalar form.
+// Also applies the one extra cull the build allows itself: a box whose
+// t_far is negative lies behind the ray origin; no triangle in it can pass `t > epsilon`,
+// so skipping it never changes a result — only the visit/test counters, which therefore
+// count after this cull (the oracle's ORC_FLAG_CULL_BEHIND mirrors it).
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void ray_box_pair(vec3 o, vec3 inv, const float4& lmin, const float4& lmax, const float4& rmin,
+                                             const float4& rmax, float t_best, bool& hit_l, bool& hit_r, float& dist_l,
+                                             float& dist_r) {
+  const f2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
+  const f2 ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
+  const f2 ax = ix * (f2{lmin.x, rmin.x} - ox), bx = ix * (f2{lmax.x, rmax.x} - ox);  // t_min.x, t_max.x of {L, R}
+  const f2 ay = iy * (f2{lmin.y, rmin.y} - oy), by = iy * (f2{lmax.y, rmax.y} - oy);
+  const f2 az = iz * (f2{lmin.z, rmin.z} - oz), bz = iz * (f2{lmax.z, rmax.z} - oz);
+  const float near_l = gmax(gmax(gmin(ax.x, bx.x), gmin(ay.x, by.x)), gmin(az.x, bz.x));
+  const float far_l = gmin(gmin(gmax(ax.x, bx.x), gmax(ay.x, by.x)), gmax(az.x, bz.x));
+  const float near_r = gmax(gmax(gmin(ax.y, bx.y), gmin(ay.y, by.y)), gmin(az.y, bz.y));
+  const float far_r = gmin(gmin(gmax(ax.y, bx.y), gmax(ay.y, by.y)), gmax(az.y, bz.y));
+  dist_l = near_l;
+  dist_r = near_r;
+  hit_l = near_l <= far_l && !(far_l < 0.0f) && near_l < t_best;  // :179, behind-origin cull, :284
+  hit_r = near_r <= far_r && !(far_r < 0.0f) && near_r < t_best;
 }
 
 // Where a traversal reads the scene from. The BVH is held as CHILD-PAIR records in
 // breadth-first order (built at upload from the reference's node array, pt_context.hip):
 // record p = {left.min, left.ref | left.max, left.cnt | right.min, right.ref | right.max,
 // right.cnt}, 64 bytes, where ref is the child's own pair record (inner) or its first
-// triangle (leaf). The first `lds_pairs` records — the top of the tree, which every ray
-// walks — and, for small scenes, the triangle positions are staged in LDS by each
-// workgroup: divergent 16-byte lane loads cost one L1 tag look-up per lane (the vector
-// memory pipe, not the VALU, bounded the first version of this kernel), while ds_read_b128
-// serves 64 lanes in a few cycles. Deeper records come from global memory.
+// triangle (leaf). IN_LDS: the scene (records + triangle positions) is small enough to be
+// staged whole in the workgroup's LDS and every fetch is a ds_read_b128; otherwise the
+// fetches are global loads (L1/L2/Infinity Cache/HBM).
 struct Tracer {
-  const float4* __restrict__ pairs;    // global, breadth-first
-  const float4* __restrict__ tri_pos;  // global, 3 x float4 per triangle
-  const float4* lds_pair;              // LDS copy of records [0, lds_pairs)
-  const float4* lds_tri;               // LDS copy of triangles [0, lds_tris)
-  uint32_t lds_pairs, lds_tris;
+  const float4* pairs;    // LDS or global, breadth-first
+  const float4* tri_pos;  // LDS or global, 3 x float4 per triangle
   uint32_t root_ref, root_cnt;
-  uint32_t* stack;                     // this lane's column of the LDS stack
+  uint32_t* stack;        // this lane's column of the LDS stack
   uint32_t stride;
 };
 
-__device__ __forceinline__ float4 pair_word(const Tracer& tr, uint32_t pair, uint32_t w) {
-  return pair < tr.lds_pairs ? tr.lds_pair[4 * pair + w] : tr.pairs[4 * static_cast<size_t>(pair) + w];
-}
-__device__ __forceinline__ float4 tri_word(const Tracer& tr, uint32_t tri, uint32_t w) {
-  return tri < tr.lds_tris ? tr.lds_tri[3 * tri + w] : tr.tri_pos[3 * static_cast<size_t>(tri) + w];
+template <bool IN_LDS>
+__device__ __forceinline__ float4 fetch16(const float4* base, uint32_t index) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (IN_LDS) {  // flat LDS address -> LDS offset (its low 32 bits): a plain ds_read_b128
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(3))) f4 lds_f4;
+    lds_f4* p = (lds_f4*)(uintptr_t)static_cast<uint32_t>(reinterpret_cast<uintptr_t>(base));
+    const f4 v = p[index];
+    return make_float4(v.x, v.y, v.z, v.w);
+  }
+#endif
+  return base[index];
 }
 
 // ray_triangle_intersect, main.comp:189-217
+template <bool IN_LDS>
 __device__ __forceinline__ void ray_triangle(const Tracer& tr, vec3 o, vec3 d, uint32_t tri, Hit& h) {
-  const vec3 p0 = xyz(tri_word(tr, tri, 0));
-  const vec3 edge1 = xyz(tri_word(tr, tri, 1)) - p0;
-  const vec3 edge2 = xyz(tri_word(tr, tri, 2)) - p0;
+  const vec3 p0 = xyz(fetch16<IN_LDS>(tr.tri_pos, 3 * tri));
+  const vec3 edge1 = xyz(fetch16<IN_LDS>(tr.tri_pos, 3 * tri + 1)) - p0;
+  const vec3 edge2 = xyz(fetch16<IN_LDS>(tr.tri_pos, 3 * tri + 2)) - p0;
   const vec3 ray_cross_edge2 = cross(d, edge2);
   const float det = dot(edge1, ray_cross_edge2);
   if (__builtin_fabsf(det) < kEpsilon) return;
@@ -219,7 +241,7 @@ __device__ __forceinline__ void ray_triangle(const Tracer& tr, vec3 o, vec3 d, u
 // ANY_HIT (shadow rays of provably all-opaque scenes): the traversal ends at the first
 // accepted triangle. The order is unchanged, so whether a hit exists is decided exactly as
 // by the full closest-hit search; h then holds *a* hit, not the closest.
-template <bool ANY_HIT>
+template <bool IN_LDS, bool ANY_HIT>
 __device__ __forceinline__ void traverse(const Tracer& tr, vec3 o, vec3 d, Hit& h, Tally& tally) {
   ++tally.rays;
   const vec3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
@@ -231,22 +253,20 @@ __device__ __forceinline__ void traverse(const Tracer& tr, vec3 o, vec3 d, Hit& 
       if (ANY_HIT) {
         for (uint32_t i = 0; i < cnt; ++i) {
           ++tally.tests;
-          ray_triangle(tr, o, d, ref + i, h);
+          ray_triangle<IN_LDS>(tr, o, d, ref + i, h);
           if (h.tri != kNoHit) return;
         }
       } else {
         tally.tests += cnt;
-        for (uint32_t i = 0; i < cnt; ++i) ray_triangle(tr, o, d, ref + i, h);
+        for (uint32_t i = 0; i < cnt; ++i) ray_triangle<IN_LDS>(tr, o, d, ref + i, h);
       }
     } else {
       ++tally.visits;
-      const float4 l0 = pair_word(tr, ref, 0), l1 = pair_word(tr, ref, 1);
-      const float4 r0 = pair_word(tr, ref, 2), r1 = pair_word(tr, ref, 3);
+      const float4 l0 = fetch16<IN_LDS>(tr.pairs, 4 * ref), l1 = fetch16<IN_LDS>(tr.pairs, 4 * ref + 1);
+      const float4 r0 = fetch16<IN_LDS>(tr.pairs, 4 * ref + 2), r1 = fetch16<IN_LDS>(tr.pairs, 4 * ref + 3);
       float dist_l, dist_r;
-      bool hit_l = ray_box(o, inv, l0, l1, dist_l);
-      bool hit_r = ray_box(o, inv, r0, r1, dist_r);
-      hit_l = hit_l && (dist_l < h.t);
-      hit_r = hit_r && (dist_r < h.t);
+      bool hit_l, hit_r;
+      ray_box_pair(o, inv, l0, l1, r0, r1, h.t, hit_l, hit_r, dist_l, dist_r);
       if (hit_l || hit_r) {
         const bool go_left = hit_l && (!hit_r || dist_l < dist_r);  // equal distances: right is near (Q14)
         if (hit_l && hit_r) {
@@ -261,27 +281,28 @@ __device__ __forceinline__ void traverse(const Tracer& tr, vec3 o, vec3 d, Hit& 
     if (sp == 0) break;
     --sp;
     const uint32_t e = tr.stack[sp * tr.stride];
-    const uint32_t pair = e >> 1, side = 2u * (e & 1u);
-    ref = fbits(pair_word(tr, pair, side).w);
-    cnt = fbits(pair_word(tr, pair, side + 1u).w);
+    const uint32_t word = 4u * (e >> 1) + 2u * (e & 1u);
+    ref = fbits(fetch16<IN_LDS>(tr.pairs, word).w);
+    cnt = fbits(fetch16<IN_LDS>(tr.pairs, word + 1u).w);
   }
 }
 
 // Workgroup prologue of the traversal kernels: carve the dynamic LDS into
-// [stack | pair records | triangles] and stage the LDS-resident part of the scene.
+// [stack | pair records | triangles] and, for IN_LDS, stage the scene.
+template <bool IN_LDS>
 __device__ __forceinline__ Tracer make_tracer(const pt_dev_scene& sc, uint32_t* lds) {
-  float4* lds_pair = reinterpret_cast<float4*>(lds + static_cast<size_t>(blockDim.x) * sc.stack_entries);
-  float4* lds_tri = lds_pair + 4 * static_cast<size_t>(sc.lds_pairs);
-  for (uint32_t i = threadIdx.x; i < 4u * sc.lds_pairs; i += blockDim.x) lds_pair[i] = sc.pairs[i];
-  for (uint32_t i = threadIdx.x; i < 3u * sc.lds_tris; i += blockDim.x) lds_tri[i] = sc.tri_pos[i];
-  __syncthreads();
   Tracer tr;
   tr.pairs = sc.pairs;
   tr.tri_pos = sc.tri_pos;
-  tr.lds_pair = lds_pair;
-  tr.lds_tri = lds_tri;
-  tr.lds_pairs = sc.lds_pairs;
-  tr.lds_tris = sc.lds_tris;
+  if (IN_LDS) {
+    float4* lds_pair = reinterpret_cast<float4*>(lds + static_cast<size_t>(blockDim.x) * sc.stack_entries);
+    float4* lds_tri = lds_pair + 4 * static_cast<size_t>(sc.pair_count);
+    for (uint32_t i = threadIdx.x; i < 4u * sc.pair_count; i += blockDim.x) lds_pair[i] = sc.pairs[i];
+    for (uint32_t i = threadIdx.x; i < 3u * sc.triangle_count; i += blockDim.x) lds_tri[i] = sc.tri_pos[i];
+    __syncthreads();
+    tr.pairs = lds_pair;
+    tr.tri_pos = lds_tri;
+  }
   tr.root_ref = sc.root_ref;
   tr.root_cnt = sc.root_cnt;
   tr.stack = lds + threadIdx.x;
@@ -567,6 +588,7 @@ __global__ __launch_bounds__(256) void k_init(pt_dev_frame f, pt_dev_state st) {
 // Closest hit for every queued ray. Persistent workgroups: the grid is a few blocks per CU
 // and each block walks the queue in strides, so the LDS scene copy is staged once per
 // block, not once per 256 rays.
+template <bool IN_LDS>
 __global__ __launch_bounds__(256) void k_extend(pt_dev_scene sc, pt_dev_state st, uint32_t parity) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
   const uint32_t n = st.counters[PT_CNT_QUEUE0 + parity];
@@ -576,12 +598,12 @@ __global__ __launch_bounds__(256) void k_extend(pt_dev_scene sc, pt_dev_state st
   }
   Tally tally;
   if (blockIdx.x * blockDim.x < n) {  // block-uniform
-    const Tracer tr = make_tracer(sc, lds_dyn);
+    const Tracer tr = make_tracer<IN_LDS>(sc, lds_dyn);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
       const uint32_t slot = st.queue[parity][i];
       const float4 o4 = st.ray_o[slot], d4 = st.ray_d[slot];
       Hit h{kInfinity, 0.0f, 0.0f, kNoHit};
-      traverse<false>(tr, xyz(o4), xyz(d4), h, tally);
+      traverse<IN_LDS, false>(tr, xyz(o4), xyz(d4), h, tally);
       st.hit[slot] = make_uint4(h.tri, fbits(h.u), fbits(h.v), fbits(h.t));
     }
   }
@@ -810,19 +832,20 @@ __global__ __launch_bounds__(256) void k_shade(pt_dev_scene sc, pt_dev_frame f, 
 
 // ray_scene_intersect_with_transparency, main.comp:306-332. Returns the transparency and
 // leaves the last traversal's result in h.
+template <bool IN_LDS>
 __device__ __forceinline__ float shadow_walk(const pt_dev_scene& sc, const Tracer& tr, vec3 origin, vec3 dir, Hit& h,
                                              Tally& tally) {
   float transparency = 1.0f;
   if (sc.all_opaque) {  // every closest hit has alpha == 1 and returns 0 (main.comp:325): any hit decides
     h.t = kInfinity;
     h.tri = kNoHit;
-    traverse<true>(tr, origin, dir, h, tally);
+    traverse<IN_LDS, true>(tr, origin, dir, h, tally);
     return h.tri == kNoHit ? 1.0f : 0.0f;
   }
   for (uint32_t step = 0; step < kMaxTransparencySteps; ++step) {
     h.t = kInfinity;
     h.tri = kNoHit;
-    traverse<false>(tr, origin, dir, h, tally);
+    traverse<IN_LDS, false>(tr, origin, dir, h, tally);
     if (h.tri == kNoHit) break;
     const vec3 wuv = mk(1.0f - h.u - h.v, h.u, h.v);
     vec3 pos;
@@ -841,12 +864,13 @@ __device__ __forceinline__ float shadow_walk(const pt_dev_scene& sc, const Trace
 
 // Shadow walks of one path vertex + the direct-lighting accumulate; finishes the sample
 // when the vertex was the path's last (light step 8).
+template <bool IN_LDS>
 __global__ __launch_bounds__(256) void k_shadow(pt_dev_scene sc, pt_dev_frame f, pt_dev_state st) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
   const uint32_t n = st.counters[PT_CNT_SHADOW];
   Tally tally;
   if (blockIdx.x * blockDim.x < n) {  // block-uniform
-  const Tracer tr = make_tracer(sc, lds_dyn);
+  const Tracer tr = make_tracer<IN_LDS>(sc, lds_dyn);
   for (uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x; gid < n; gid += gridDim.x * blockDim.x) {
     const uint32_t slot = st.shadow_queue[gid];
     const float4* hdr = st.shadow_hdr + 4 * static_cast<size_t>(slot);
@@ -861,7 +885,7 @@ __global__ __launch_bounds__(256) void k_shadow(pt_dev_scene sc, pt_dev_frame f,
     for (uint32_t k = 0; k < n_lights; ++k, rec += 4) {
       const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
       Hit h{kInfinity, 0.0f, 0.0f, kNoHit};
-      const float transparency = shadow_walk(sc, tr, origin, xyz(r0), h, tally);
+      const float transparency = shadow_walk<IN_LDS>(sc, tr, origin, xyz(r0), h, tally);
       if (transparency == 0.0f) continue;                                   // :423 / :446 / :486
       if (h.tri != kNoHit && h.t + r1.w < r0.w) continue;                   // :448 / :488
       vec3 radiance = xyz(r1);
@@ -933,14 +957,16 @@ void launch_init(const pt_dev_frame& f, const pt_dev_state& st, hipStream_t s) {
 }
 
 static inline size_t trace_lds_bytes(const pt_dev_scene& sc, uint32_t block) {
-  return static_cast<size_t>(block) * sc.stack_entries * sizeof(uint32_t) + 64u * sc.lds_pairs + 48u * sc.lds_tris;
+  return static_cast<size_t>(block) * sc.stack_entries * sizeof(uint32_t) +
+         (sc.scene_in_lds ? 64u * static_cast<size_t>(sc.pair_count) + 48u * static_cast<size_t>(sc.triangle_count) : 0u);
 }
 
 void launch_extend(const pt_dev_scene& sc, const pt_dev_state& st, uint32_t parity, uint32_t max_entries, uint32_t block,
                    uint32_t max_blocks, hipStream_t s) {
   uint32_t grid = blocks_for(max_entries, block);
   if (grid > max_blocks) grid = max_blocks;
-  hipLaunchKernelGGL(k_extend, dim3(grid), dim3(block), trace_lds_bytes(sc, block), s, sc, st, parity);
+  if (sc.scene_in_lds) hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(block), trace_lds_bytes(sc, block), s, sc, st, parity);
+  else hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(block), trace_lds_bytes(sc, block), s, sc, st, parity);
 }
 
 void launch_shade(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity,
@@ -952,7 +978,8 @@ void launch_shadow(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_s
                    uint32_t block, uint32_t max_blocks, hipStream_t s) {
   uint32_t grid = blocks_for(max_entries, block);
   if (grid > max_blocks) grid = max_blocks;
-  hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(block), trace_lds_bytes(sc, block), s, sc, f, st);
+  if (sc.scene_in_lds) hipLaunchKernelGGL(k_shadow<true>, dim3(grid), dim3(block), trace_lds_bytes(sc, block), s, sc, f, st);
+  else hipLaunchKernelGGL(k_shadow<false>, dim3(grid), dim3(block), trace_lds_bytes(sc, block), s, sc, f, st);
 }
 
 void launch_finalize(const pt_dev_frame& f, const pt_dev_state& st, float4* accum_out, uint32_t* primary_out, hipStream_t s) {

@@ -28,6 +28,8 @@ def load():
 
 
 ANYHIT_OPAQUE_SHADOW = 1
+CULL_BEHIND = 2
+GPU_MIRROR = ANYHIT_OPAQUE_SHADOW | CULL_BEHIND  # the checker modes that reproduce the HIP path's work counters
 
 
 def render(lib, packed, rp, threads=8, rows=None, want_ids=True, flags=0):

@@ -30,7 +30,7 @@ def compare(renderer, oracle, scene, w, h, spp, seed, rank=0, num_ranks=1, rows=
     rp = packed.render_params(renderer.lib, w, h, spp, bg, seed, rank, num_ranks)
     rgba, accum, ids, st = renderer.render_params(rp)
     # the oracle in the reference's own form (full closest-hit shadow walks) pins the images;
-    # its any-hit mirror (identical images, CPU-tested) pins the GPU's work counters
+    # its checker modes (any-hit shadow rays, behind-origin cull: identical images, CPU-tested) pins the GPU's work counters
     o_rgba, o_accum, o_ids, _ = oracle_lib.render(oracle, packed, rp, threads=8, rows=rows)
     sl = slice(*rows) if rows else slice(None)
     id_agree = float((ids[sl] == o_ids[sl]).mean())
@@ -39,7 +39,7 @@ def compare(renderer, oracle, scene, w, h, spp, seed, rank=0, num_ranks=1, rows=
     assert not mism.any(), f"{mism.any(axis=-1).sum()} pixels differ; first {np.argwhere(mism)[:3]}"
     assert (rgba[sl] == o_rgba[sl]).all()
     if rows is None:
-        o_st = oracle_lib.render(oracle, packed, rp, threads=8, flags=oracle_lib.ANYHIT_OPAQUE_SHADOW)[3]
+        o_st = oracle_lib.render(oracle, packed, rp, threads=8, flags=oracle_lib.GPU_MIRROR)[3]
         for k in COUNTERS:
             assert st[k] == o_st[k], (k, st[k], o_st[k])
     return st

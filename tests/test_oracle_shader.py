@@ -48,6 +48,20 @@ def test_anyhit_checker_mode_gives_identical_images(oracle):
         assert b[3]["node_visits"] <= a[3]["node_visits"] and b[3]["tri_tests"] <= a[3]["tri_tests"]
 
 
+def test_behind_origin_cull_checker_mode_gives_identical_images(oracle):
+    for s in [scenes.cornell_scene(True, True, True, True), scenes.textured_scene(),
+              scenes.soup_scene(3000, seed=4, emissive_every=40), scenes.cube_scene()]:
+        p = PackedScene(s, oracle, "orc_")
+        rp = p.render_params(oracle, 80, 48, 9, seed=22, prefix="orc_")
+        a = oracle_lib.render(oracle, p, rp)
+        b = oracle_lib.render(oracle, p, rp, flags=oracle_lib.CULL_BEHIND)
+        assert a[1].tobytes() == b[1].tobytes() and a[0].tobytes() == b[0].tobytes()
+        assert (a[2] == b[2]).all()
+        for k in ("paths", "rays", "shaded_vertices", "hits_shaded", "texture_taps", "nan_samples"):
+            assert a[3][k] == b[3][k]
+        assert b[3]["node_visits"] < a[3]["node_visits"] and b[3]["tri_tests"] <= a[3]["tri_tests"]
+
+
 def test_non_opaque_scenes_are_not_flagged(oracle):
     for s in [scenes.cornell_scene(glass_pane=True), scenes.textured_scene()]:
         p = PackedScene(s, oracle, "orc_")
