@@ -179,6 +179,9 @@ def main() -> None:
         step(abi.FLAG_TIME_KERNELS)
         torch.cuda.synchronize(dev)
         sd = stats.as_dict()
+        if sd["shadow"]["launches"] == 0:  # the shadow walks run inside k_shade: their traversal work belongs to it
+            for k in ("rays", "node_visits", "tri_tests", "hits_shaded", "texture_taps"):
+                sd["shade"][k] += sd["shadow"][k]
         kernels = {k: kernel_roofline(k, sd[k], sd["shaded_vertices"]) for k in ("extend", "shade", "shadow") if sd[k]["launches"]}
         dominant = max(kernels, key=lambda k: sd[k]["ms"])
         roof = dict(kernels[dominant]["hbm"])

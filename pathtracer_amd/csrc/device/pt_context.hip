@@ -187,11 +187,8 @@ int ensure_state(pt_ctx* ctx, uint32_t slots, uint32_t lights, uint32_t pixels) 
   ALLOC(st.path_b, slots);
   ALLOC(st.accum, slots);
   ALLOC(st.primary_id, slots);
-  ALLOC(st.shadow_hdr, lights ? 4 * static_cast<size_t>(slots) : 1);
-  ALLOC(st.shadow_rec, 4 * static_cast<size_t>(slots) * lights);
   ALLOC(st.queue[0], slots);
   ALLOC(st.queue[1], slots);
-  ALLOC(st.shadow_queue, slots);
   ALLOC(st.counters, PT_CNT_WORDS);
   st.stat_rows = slots / 64 + 1;
   ALLOC(st.stats, static_cast<size_t>(PT_K_COUNT) * st.stat_rows * PT_ST_WORDS);
@@ -525,8 +522,7 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
       for (uint32_t b = 0; b < kBatch; ++b, ++iter) {
         const uint32_t parity = static_cast<uint32_t>(iter & 1u);
         timed(PT_K_EXTEND, [&] { ptd::launch_extend(sc, st, parity, bound, trace_block, ctx->trace_blocks, stream); });
-        timed(PT_K_SHADE, [&] { ptd::launch_shade(sc, f, st, parity, bound, stream); });
-        if (n_lights) timed(PT_K_SHADOW, [&] { ptd::launch_shadow(sc, f, st, bound, trace_block, ctx->trace_blocks, stream); });
+        timed(PT_K_SHADE, [&] { ptd::launch_shade(sc, f, st, parity, bound, trace_block, ctx->trace_blocks, n_lights != 0, stream); });
       }
       PT_HIP(ctx, hipGetLastError());
       // entries queued for the NEXT iteration; stays intact until that iteration's successor recycles it

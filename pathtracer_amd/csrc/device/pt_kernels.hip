@@ -93,7 +93,8 @@ __device__ __forceinline__ AppendSlots block_append2(bool pred_a, uint32_t* coun
   __syncthreads();
   if (threadIdx.x < 2) {
     const uint32_t q = threadIdx.x;
-    const uint32_t total = wave_count[q][0] + wave_count[q][1] + wave_count[q][2] + wave_count[q][3];
+    uint32_t total = 0;
+    for (uint32_t i = 0; i < (blockDim.x >> 6); ++i) total += wave_count[q][i];
     uint32_t* counter = q ? counter_b : counter_a;
     block_base[q] = (total && counter) ? atomicAdd(counter, total) : 0u;
   }
@@ -138,6 +139,7 @@ __device__ __forceinline__ void flush_tally(const Tally& t, const pt_dev_state& 
       row[threadIdx.x] += s;
     }
   }
+  __syncthreads();  // `part` may be reused by a second flush
 }
 
 // ---------------------------------------------------------------- traversal
@@ -480,18 +482,18 @@ __device__ __forceinline__ vec3 uniform_hemisphere_sampling(vec3 n, uint32_t& rn
   return to_world(orthogonal_matrix(n), mk(cp * sin_theta, sp * sin_theta, cos_theta));
 }
 
-__device__ __forceinline__ vec3 diffuse_sample(vec3 n, uint32_t& rng, float& pdf) {
+__device__ __forceinline__ vec3 diffuse_sample(vec3 n, const Basis& basis, uint32_t& rng, float& pdf) {
   const float phi = 2.0f * kPi * rand_float(rng);
   const float rnd = rand_float(rng);
   float sp, cp;
   pt_sincos(phi, &sp, &cp);
   const float sr = __builtin_sqrtf(rnd);
-  const vec3 l = to_world(orthogonal_matrix(n), mk(cp * sr, sp * sr, __builtin_sqrtf(1.0f - rnd)));
+  const vec3 l = to_world(basis, mk(cp * sr, sp * sr, __builtin_sqrtf(1.0f - rnd)));
   pdf = gmax(dot(n, l), 0.0f) / kPi;
   return l;
 }
 
-__device__ __forceinline__ vec3 microfacet_sample(vec3 n, vec3 v, float a2, uint32_t& rng, float& pdf) {
+__device__ __forceinline__ vec3 microfacet_sample(const Basis& basis, vec3 v, float a2, uint32_t& rng, float& pdf) {
   const float phi = 2.0f * kPi * rand_float(rng);
   const float rnd = rand_float(rng);
   const float cos2_theta = gmin(gmax((1.0f - rnd) / (rnd * (a2 - 1.0f) + 1.0f), 0.0f), 1.0f);
@@ -499,7 +501,7 @@ __device__ __forceinline__ vec3 microfacet_sample(vec3 n, vec3 v, float a2, uint
   const float sin_theta = __builtin_sqrtf(1.0f - cos2_theta);
   float sp, cp;
   pt_sincos(phi, &sp, &cp);
-  const vec3 h = normalize(to_world(orthogonal_matrix(n), mk(cp * sin_theta, sp * sin_theta, cos_theta)));
+  const vec3 h = normalize(to_world(basis, mk(cp * sin_theta, sp * sin_theta, cos_theta)));
   const vec3 i = -v;
   const vec3 l = i - h * (2.0f * dot(h, i));  // reflect(-v, h)
   pdf = distribution_ggx(cos_theta, a2) * cos_theta / (4.0f * __builtin_fabsf(dot(h, l)));
@@ -594,7 +596,6 @@ __global__ __launch_bounds__(256) void k_extend(pt_dev_scene sc, pt_dev_state st
   const uint32_t n = st.counters[PT_CNT_QUEUE0 + parity];
   if (blockIdx.x == 0 && threadIdx.x == 0) {  // recycle the counters the previous iteration consumed
     st.counters[PT_CNT_QUEUE0 + (parity ^ 1u)] = 0;
-    st.counters[PT_CNT_SHADOW] = 0;
   }
   Tally tally;
   if (blockIdx.x * blockDim.x < n) {  // block-uniform
@@ -608,226 +609,6 @@ __global__ __launch_bounds__(256) void k_extend(pt_dev_scene sc, pt_dev_state st
     }
   }
   flush_tally(tally, st, PT_K_EXTEND);
-}
-
-// trace() loop body for every extended ray.
-__global__ __launch_bounds__(256) void k_shade(pt_dev_scene sc, pt_dev_frame f, pt_dev_state st, uint32_t parity) {
-  const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t n = st.counters[PT_CNT_QUEUE0 + parity];
-  const bool active = gid < n;
-  Tally tally;
-  bool alive = false;       // slot continues with a ray next iteration
-  bool wants_shadow = false;
-  uint32_t slot = 0;
-
-  if (active) {
-    slot = st.queue[parity][gid];
-    const uint4 hw = st.hit[slot];
-    const float4 pa = st.path_a[slot];
-    float4 pb = st.path_b[slot];
-    vec3 indirect = xyz(pa);
-    uint32_t rng = fbits(pa.w);
-    vec3 color = xyz(pb);
-    uint32_t ctr = fbits(pb.w);
-    uint32_t light_steps = ctr_light(ctr), transp_steps = ctr_transp(ctr), sample = ctr_sample(ctr);
-    const vec3 bg_linear = mk(f.bg_linear[0], f.bg_linear[1], f.bg_linear[2]);
-
-    if (ctr_primary(ctr)) st.primary_id[slot] = hw.x;
-
-    bool path_done = false;     // the sample ends at this vertex
-    bool deferred_finish = false;  // ... and k_shadow finishes it (it owns `color` then)
-    vec3 next_o = mk(0, 0, 0), next_d = mk(0, 0, 0);
-
-    if (hw.x == kNoHit) {  // main.comp:517 -> :580
-      float4 acc = st.accum[slot];
-      finish_sample(color, indirect, bg_linear, acc, tally);
-      st.accum[slot] = acc;
-      path_done = true;
-    } else {
-      const float4 d4 = st.ray_d[slot];
-      const vec3 ray_dir = xyz(d4);
-      const float hu = ubits(hw.y), hv = ubits(hw.z);
-      const vec3 wuv = mk(1.0f - hu - hv, hu, hv);
-      vec3 pos, nrm;
-      float tu, tv;
-      uint32_t mat_idx;
-      interpolate_pos_uv(sc, hw.x, wuv, pos, tu, tv, mat_idx, &nrm, tally);
-      if (dot(nrm, ray_dir) > 0.0f) nrm = nrm * -1.0f;  // main.comp:524
-
-      // get_material_data, main.comp:242-259
-      const Material m = load_material(sc.materials, mat_idx);
-      const float4 bc = sample_texture(sc, m.base_tex, tu, tv, tally);
-      const vec3 base_color = mk(m.base_color.x, m.base_color.y, m.base_color.z) * decode_srgb(m.base_tex, bc);
-      const float alpha = m.base_color.w * bc.w;
-      const float4 mr = sample_texture(sc, m.mr_tex, tu, tv, tally);
-      const float metal = m.metallic * mr.z;
-      const float roughness = m.roughness * mr.y;
-      const float4 em = sample_texture(sc, m.emissive_tex, tu, tv, tally);
-      const vec3 emission = m.emissive * decode_srgb(m.emissive_tex, em);
-      const float4 oc = sample_texture(sc, m.occlusion_tex, tu, tv, tally);
-      const float occlusion = 1.0f + m.occlusion_strength * (oc.x - 1.0f);
-      const float a = roughness * roughness;
-      const float a2 = a * a;
-      ++tally.verts;
-
-      const vec3 view = -ray_dir;
-      const vec3 shadow_origin = pos + kNormalDelta * nrm;
-      const uint32_t n_lights = sc.directional_light_count + sc.point_light_count + (f.pc.emissive_triangle_count ? 1u : 0u);
-      float4* rec = st.shadow_rec + 4 * static_cast<size_t>(slot) * n_lights;
-
-      // sample_punctual_light set-up, main.comp:409-457: everything up to the shadow walk
-      for (uint32_t i = 0; i < sc.directional_light_count; ++i) {
-        const float4 l0 = sc.directional_lights[2 * i], l1 = sc.directional_lights[2 * i + 1];
-        const vec3 l = -xyz(l1);
-        const float n_dot_l = gmax(dot(nrm, l), 0.0f);
-        const vec3 radiance = xyz(l0) * l0.w;
-        const vec3 brdf = microfacet_brdf(nrm, view, l, metal, a2, base_color);
-        rec[0] = make_float4(l.x, l.y, l.z, -__builtin_inff());  // no distance test for directional lights
-        rec[1] = make_float4(radiance.x, radiance.y, radiance.z, 0.0f);
-        rec[2] = make_float4(brdf.x, brdf.y, brdf.z, n_dot_l);
-        rec[3] = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
-        rec += 4;
-      }
-      for (uint32_t i = 0; i < sc.point_light_count; ++i) {
-        const float4 l0 = sc.point_lights[2 * i], l1 = sc.point_lights[2 * i + 1];
-        const vec3 lpos = xyz(l1);
-        const vec3 sample_dir = uniform_hemisphere_sampling(normalize(pos - lpos), rng);
-        const vec3 sample_pos = lpos + sample_dir * kPointLightRadius;
-        vec3 l = sample_pos - pos;
-        const float dist2 = dot(l, l);
-        l = normalize(l);
-        const float correction = kNormalDelta / dot(l, nrm);
-        const vec3 radiance = xyz(l0) * l0.w / kLightArea / kFourPi;
-        const float cos_theta0 = dot(sample_dir, -l);
-        const float pdf = dist2 / (cos_theta0 * kLightArea);
-        const float n_dot_l = __builtin_fabsf(dot(nrm, l));
-        const vec3 brdf = microfacet_brdf(nrm, view, l, metal, a2, base_color);
-        rec[0] = make_float4(l.x, l.y, l.z, length(pos - sample_pos));
-        rec[1] = make_float4(radiance.x, radiance.y, radiance.z, correction);
-        rec[2] = make_float4(brdf.x, brdf.y, brdf.z, n_dot_l);
-        rec[3] = make_float4(pdf, 0.0f, 0.0f, 0.0f);
-        rec += 4;
-      }
-      // sample_area_light set-up, main.comp:464-500
-      if (f.pc.emissive_triangle_count) {
-        const uint32_t count = f.pc.emissive_triangle_count;
-        uint32_t pick = static_cast<uint32_t>(rand_float(rng) * static_cast<float>(count));
-        if (pick > count - 1) pick = count - 1;  // Q3: rand_float may be exactly 1.0
-        const uint32_t etri = sc.emissive_triangles[pick];
-        float su = rand_float(rng), sv = rand_float(rng);  // sample_triangle, main.comp:158-165
-        if (su + sv > 1.0f) {
-          su = 1.0f - su;
-          sv = 1.0f - sv;
-        }
-        const vec3 ewuv = mk(1.0f - su - sv, su, sv);
-        vec3 tri_pos, tri_n;
-        float eu, ev;
-        uint32_t emat_idx;
-        interpolate_pos_uv(sc, etri, ewuv, tri_pos, eu, ev, emat_idx, &tri_n, tally);
-        vec3 l = tri_pos - pos;
-        const float dist2 = dot(l, l);
-        l = normalize(l);
-        if (dot(l, tri_n) > 0.0f) tri_n = tri_n * -1.0f;
-        const float correction = kNormalDelta / dot(l, nrm);
-        const float4 q0 = sc.tri_pos[3 * static_cast<size_t>(etri)];
-        const float4 q1 = sc.tri_pos[3 * static_cast<size_t>(etri) + 1];
-        const float4 q2 = sc.tri_pos[3 * static_cast<size_t>(etri) + 2];
-        const float area = length(cross(xyz(q1) - xyz(q0), xyz(q2) - xyz(q0))) / 2.0f;
-        const float cos_theta0 = dot(tri_n, -l);
-        const float pdf = dist2 / (cos_theta0 * area) / static_cast<float>(count);
-        const float n_dot_l = __builtin_fabsf(dot(nrm, l));
-        const vec3 brdf = microfacet_brdf(nrm, view, l, metal, a2, base_color);
-        // the emitter's emission (material + texture fetch, main.comp:497-498) is only
-        // evaluated if the shadow walk lets the sample through: k_shadow does it
-        rec[0] = make_float4(l.x, l.y, l.z, length(pos - tri_pos));
-        rec[1] = make_float4(eu, ev, ubits(emat_idx), correction);
-        rec[2] = make_float4(brdf.x, brdf.y, brdf.z, n_dot_l);
-        rec[3] = make_float4(pdf, 0.0f, 0.0f, 0.0f);
-      }
-
-      const vec3 indirect_pre = indirect * occlusion;  // main.comp:540
-      indirect = indirect_pre;
-      float weight;  // `alpha` on the pass-through branch, 1 otherwise (1 * x == x)
-      if (alpha < 1.0f && transp_steps < kMaxTransparencySteps) {  // main.comp:542-547
-        ++transp_steps;
-        weight = alpha;
-        indirect = indirect * (1.0f - alpha);
-        next_o = pos + kNormalDelta * ray_dir;
-        next_d = ray_dir;
-      } else {  // main.comp:549-577
-        ++light_steps;
-        weight = 1.0f;
-        float diffuse_pdf, microfacet_pdf;
-        const vec3 diffuse_dir = diffuse_sample(nrm, rng, diffuse_pdf);
-        const vec3 microfacet_dir = microfacet_sample(nrm, view, a2, rng, microfacet_pdf);
-        vec3 dir;
-        float c;
-        if (rand_float(rng) < metal) {
-          dir = microfacet_dir;
-          c = metal;
-        } else {
-          dir = diffuse_dir;
-          c = 1.0f - metal;
-        }
-        const float pdf = c * (diffuse_pdf + microfacet_pdf);
-        const float n_dot_l = gmax(dot(nrm, dir), 0.0f);
-        indirect = indirect * (microfacet_brdf(nrm, view, dir, metal, a2, base_color) * n_dot_l / pdf);
-        next_o = shadow_origin;
-        next_d = dir;
-      }
-      path_done = light_steps >= kMaxLightSteps;  // main.comp:512
-
-      if (n_lights == 0) {
-        // no light of any kind: direct = emission + vec3(0) + vec3(0) (main.comp:536-538)
-        const vec3 direct = (emission + splat(0.0f)) + splat(0.0f);
-        color = color + direct * weight * indirect_pre;  // :545 / :552
-        if (path_done) {
-          float4 acc = st.accum[slot];
-          finish_sample(color, indirect, bg_linear, acc, tally);
-          st.accum[slot] = acc;
-        }
-      } else {
-        wants_shadow = true;
-        deferred_finish = path_done;
-        float4* hdr = st.shadow_hdr + 4 * static_cast<size_t>(slot);
-        hdr[0] = make_float4(emission.x, emission.y, emission.z, weight);
-        hdr[1] = make_float4(indirect_pre.x, indirect_pre.y, indirect_pre.z, path_done ? 1.0f : 0.0f);
-        hdr[2] = make_float4(indirect.x, indirect.y, indirect.z, 0.0f);
-        hdr[3] = make_float4(shadow_origin.x, shadow_origin.y, shadow_origin.z, 0.0f);
-      }
-    }
-
-    if (path_done) {  // next stratum of this pixel, or retire the slot (main():597-598)
-      ++sample;
-      if (sample < f.sample_end) {
-        uint32_t x, y;
-        slot_to_pixel(f, slot, x, y);
-        camera_ray(f, x, y, sample, rng, next_o, next_d);
-        ++tally.paths;
-        alive = true;
-      }
-      indirect = splat(1.0f);
-      if (!deferred_finish) color = splat(0.0f);  // otherwise k_shadow still needs it and zeroes it itself
-      light_steps = 0;
-      transp_steps = 0;
-    } else {
-      alive = true;
-    }
-
-    if (alive) {
-      st.ray_o[slot] = make_float4(next_o.x, next_o.y, next_o.z, 0.0f);
-      st.ray_d[slot] = make_float4(next_d.x, next_d.y, next_d.z, 0.0f);
-    }
-    st.path_a[slot] = make_float4(indirect.x, indirect.y, indirect.z, ubits(rng));
-    pb = make_float4(color.x, color.y, color.z, ubits(ctr_pack(light_steps, transp_steps, false, sample)));
-    st.path_b[slot] = pb;
-  }
-
-  // queue compaction (the whole block converges here)
-  const AppendSlots at = block_append2(alive, &st.counters[PT_CNT_QUEUE0 + (parity ^ 1u)], wants_shadow, &st.counters[PT_CNT_SHADOW]);
-  if (alive) st.queue[parity ^ 1u][at.a] = slot;
-  if (wants_shadow) st.shadow_queue[at.b] = slot;
-  flush_tally(tally, st, PT_K_SHADE);
 }
 
 // ray_scene_intersect_with_transparency, main.comp:306-332. Returns the transparency and
@@ -862,59 +643,224 @@ __device__ __forceinline__ float shadow_walk(const pt_dev_scene& sc, const Trace
   return transparency;
 }
 
-// Shadow walks of one path vertex + the direct-lighting accumulate; finishes the sample
-// when the vertex was the path's last (light step 8).
+// trace() loop body (main.comp:517-577) for every extended ray: miss handling, interpolation,
+// material, light sampling WITH its shadow walks, BSDF sampling, sample bookkeeping and
+// path regeneration (main():597-612), then compaction of the survivors into the next queue.
+// The shadow walks run here rather than in a kernel of their own: a separate shadow kernel
+// needed a 112-byte request per vertex and light written and read back through HBM, and
+// had to evaluate the BRDF, pdf and emitter data of every light sample up front although
+// they only matter for the few samples the walk lets through (measured: DESIGN.md).
+// Persistent workgroups striding the queue, so the LDS scene copy is staged once per block.
 template <bool IN_LDS>
-__global__ __launch_bounds__(256) void k_shadow(pt_dev_scene sc, pt_dev_frame f, pt_dev_state st) {
+__global__ __launch_bounds__(256) void k_shade(pt_dev_scene sc, pt_dev_frame f, pt_dev_state st, uint32_t parity) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
-  const uint32_t n = st.counters[PT_CNT_SHADOW];
-  Tally tally;
-  if (blockIdx.x * blockDim.x < n) {  // block-uniform
-  const Tracer tr = make_tracer<IN_LDS>(sc, lds_dyn);
-  for (uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x; gid < n; gid += gridDim.x * blockDim.x) {
-    const uint32_t slot = st.shadow_queue[gid];
-    const float4* hdr = st.shadow_hdr + 4 * static_cast<size_t>(slot);
-    const float4 h0 = hdr[0], h1 = hdr[1], h3 = hdr[3];
-    const vec3 origin = xyz(h3);
-    const uint32_t n_punctual = sc.directional_light_count + sc.point_light_count;
-    const uint32_t n_lights = n_punctual + (f.pc.emissive_triangle_count ? 1u : 0u);
-    const float4* rec = st.shadow_rec + 4 * static_cast<size_t>(slot) * n_lights;
+  const uint32_t n = st.counters[PT_CNT_QUEUE0 + parity];
+  Tally tally;   // shading work
+  Tally walks;   // the shadow walks' traversal work (reported as the `shadow` slice)
+  const uint32_t n_lights = sc.directional_light_count + sc.point_light_count + (f.pc.emissive_triangle_count ? 1u : 0u);
+  Tracer tr{};
+  if (n_lights && blockIdx.x * blockDim.x < n) tr = make_tracer<IN_LDS>(sc, lds_dyn);  // block-uniform
+  const vec3 bg_linear = mk(f.bg_linear[0], f.bg_linear[1], f.bg_linear[2]);
 
-    vec3 punctual = splat(0.0f);  // sample_punctual_light's `color`, main.comp:410
-    vec3 area = splat(0.0f);
-    for (uint32_t k = 0; k < n_lights; ++k, rec += 4) {
-      const float4 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
-      Hit h{kInfinity, 0.0f, 0.0f, kNoHit};
-      const float transparency = shadow_walk<IN_LDS>(sc, tr, origin, xyz(r0), h, tally);
-      if (transparency == 0.0f) continue;                                   // :423 / :446 / :486
-      if (h.tri != kNoHit && h.t + r1.w < r0.w) continue;                   // :448 / :488
-      vec3 radiance = xyz(r1);
-      if (k >= n_punctual) {  // area light: emission of the sampled emitter, main.comp:497-498
-        const Material emat = load_material(sc.materials, fbits(r1.z));
-        const float4 et = sample_texture(sc, emat.emissive_tex, r1.x, r1.y, tally);
-        radiance = emat.emissive * decode_srgb(emat.emissive_tex, et);
+  for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {  // block-uniform trip count
+    const uint32_t gid = base + threadIdx.x;
+    const bool active = gid < n;
+    bool alive = false;  // slot continues with a ray next iteration
+    uint32_t slot = 0;
+
+    if (active) {
+      slot = st.queue[parity][gid];
+      const uint4 hw = st.hit[slot];
+      const float4 pa = st.path_a[slot];
+      const float4 pb = st.path_b[slot];
+      vec3 indirect = xyz(pa);
+      uint32_t rng = fbits(pa.w);
+      vec3 color = xyz(pb);
+      const uint32_t ctr = fbits(pb.w);
+      uint32_t light_steps = ctr_light(ctr), transp_steps = ctr_transp(ctr), sample = ctr_sample(ctr);
+
+      if (ctr_primary(ctr)) st.primary_id[slot] = hw.x;
+
+      bool path_done = false;  // the sample ends at this vertex
+      vec3 next_o = mk(0, 0, 0), next_d = mk(0, 0, 0);
+
+      if (hw.x == kNoHit) {  // main.comp:517 -> :580
+        path_done = true;
+      } else {
+        const float4 d4 = st.ray_d[slot];
+        const vec3 ray_dir = xyz(d4);
+        const float hu = ubits(hw.y), hv = ubits(hw.z);
+        const vec3 wuv = mk(1.0f - hu - hv, hu, hv);
+        vec3 pos, nrm;
+        float tu, tv;
+        uint32_t mat_idx;
+        interpolate_pos_uv(sc, hw.x, wuv, pos, tu, tv, mat_idx, &nrm, tally);
+        if (dot(nrm, ray_dir) > 0.0f) nrm = nrm * -1.0f;  // main.comp:524
+
+        // get_material_data, main.comp:242-259
+        const Material m = load_material(sc.materials, mat_idx);
+        const float4 bc = sample_texture(sc, m.base_tex, tu, tv, tally);
+        const vec3 base_color = mk(m.base_color.x, m.base_color.y, m.base_color.z) * decode_srgb(m.base_tex, bc);
+        const float alpha = m.base_color.w * bc.w;
+        const float4 mr = sample_texture(sc, m.mr_tex, tu, tv, tally);
+        const float metal = m.metallic * mr.z;
+        const float roughness = m.roughness * mr.y;
+        const float4 em = sample_texture(sc, m.emissive_tex, tu, tv, tally);
+        const vec3 emission = m.emissive * decode_srgb(m.emissive_tex, em);
+        const float4 oc = sample_texture(sc, m.occlusion_tex, tu, tv, tally);
+        const float occlusion = 1.0f + m.occlusion_strength * (oc.x - 1.0f);
+        const float a = roughness * roughness;
+        const float a2 = a * a;
+        ++tally.verts;
+
+        const vec3 view = -ray_dir;
+        const vec3 shadow_origin = pos + kNormalDelta * nrm;
+
+        // sample_punctual_light, main.comp:409-460
+        vec3 punctual = splat(0.0f);
+        for (uint32_t i = 0; i < sc.directional_light_count; ++i) {
+          const float4 l0 = sc.directional_lights[2 * i], l1 = sc.directional_lights[2 * i + 1];
+          const vec3 l = -xyz(l1);
+          Hit sh{kInfinity, 0.0f, 0.0f, kNoHit};
+          const float transparency = shadow_walk<IN_LDS>(sc, tr, shadow_origin, l, sh, walks);
+          if (transparency == 0.0f) continue;
+          const float n_dot_l = gmax(dot(nrm, l), 0.0f);
+          const vec3 radiance = xyz(l0) * l0.w * transparency;
+          punctual = punctual + radiance * microfacet_brdf(nrm, view, l, metal, a2, base_color) * n_dot_l;
+        }
+        for (uint32_t i = 0; i < sc.point_light_count; ++i) {
+          const float4 l0 = sc.point_lights[2 * i], l1 = sc.point_lights[2 * i + 1];
+          const vec3 lpos = xyz(l1);
+          const vec3 sample_dir = uniform_hemisphere_sampling(normalize(pos - lpos), rng);
+          const vec3 sample_pos = lpos + sample_dir * kPointLightRadius;
+          vec3 l = sample_pos - pos;
+          const float dist2 = dot(l, l);
+          l = normalize(l);
+          Hit sh{kInfinity, 0.0f, 0.0f, kNoHit};
+          const float transparency = shadow_walk<IN_LDS>(sc, tr, shadow_origin, l, sh, walks);
+          if (transparency == 0.0f) continue;
+          const float correction = kNormalDelta / dot(l, nrm);
+          if (sh.tri != kNoHit && sh.t + correction < length(pos - sample_pos)) continue;
+          const vec3 radiance = xyz(l0) * l0.w / kLightArea / kFourPi * transparency;
+          const float cos_theta0 = dot(sample_dir, -l);
+          const float pdf = dist2 / (cos_theta0 * kLightArea);
+          const float n_dot_l = __builtin_fabsf(dot(nrm, l));
+          punctual = punctual + radiance * microfacet_brdf(nrm, view, l, metal, a2, base_color) * n_dot_l / pdf;
+        }
+
+        // sample_area_light, main.comp:464-501
+        vec3 area_light = splat(0.0f);
+        if (f.pc.emissive_triangle_count) {
+          const uint32_t count = f.pc.emissive_triangle_count;
+          uint32_t pick = static_cast<uint32_t>(rand_float(rng) * static_cast<float>(count));
+          if (pick > count - 1) pick = count - 1;  // Q3: rand_float may be exactly 1.0
+          const uint32_t etri = sc.emissive_triangles[pick];
+          float su = rand_float(rng), sv = rand_float(rng);  // sample_triangle, main.comp:158-165
+          if (su + sv > 1.0f) {
+            su = 1.0f - su;
+            sv = 1.0f - sv;
+          }
+          const vec3 ewuv = mk(1.0f - su - sv, su, sv);
+          // get_interpolated_data of the emitter; its normal, uv and material are only needed
+          // if the walk lets the sample through, so only the position is formed here
+          ++tally.hits;
+          const float4 q0 = sc.tri_pos[3 * static_cast<size_t>(etri)];
+          const float4 q1 = sc.tri_pos[3 * static_cast<size_t>(etri) + 1];
+          const float4 q2 = sc.tri_pos[3 * static_cast<size_t>(etri) + 2];
+          const vec3 tri_pos = mat3_mul(xyz(q0), xyz(q1), xyz(q2), ewuv);
+          vec3 l = tri_pos - pos;
+          const float dist2 = dot(l, l);
+          l = normalize(l);
+          Hit sh{kInfinity, 0.0f, 0.0f, kNoHit};
+          const float transparency = shadow_walk<IN_LDS>(sc, tr, shadow_origin, l, sh, walks);
+          const float correction = kNormalDelta / dot(l, nrm);
+          if (transparency != 0.0f && !(sh.tri != kNoHit && sh.t + correction < length(pos - tri_pos))) {
+            const TriAttr at = load_attr(sc.tri_attr, etri);
+            vec3 tri_n = normalize(mat3_mul(at.n0, at.n1, at.n2, ewuv));
+            const float eu = at.u0 * ewuv.x + at.u1 * ewuv.y + at.u2 * ewuv.z;
+            const float ev = at.v0 * ewuv.x + at.v1 * ewuv.y + at.v2 * ewuv.z;
+            if (dot(l, tri_n) > 0.0f) tri_n = tri_n * -1.0f;
+            const float area = length(cross(xyz(q1) - xyz(q0), xyz(q2) - xyz(q0))) / 2.0f;
+            const float cos_theta0 = dot(tri_n, -l);
+            const float pdf = dist2 / (cos_theta0 * area) / static_cast<float>(count);
+            const float n_dot_l = __builtin_fabsf(dot(nrm, l));
+            const Material emat = load_material(sc.materials, at.mat);
+            const float4 et = sample_texture(sc, emat.emissive_tex, eu, ev, tally);
+            const vec3 e_emission = emat.emissive * decode_srgb(emat.emissive_tex, et) * transparency;
+            area_light = e_emission * microfacet_brdf(nrm, view, l, metal, a2, base_color) * n_dot_l / pdf;
+          }
+        }
+
+        vec3 direct = emission;        // main.comp:536
+        direct = direct + punctual;    // :537
+        direct = direct + area_light;  // :538
+        indirect = indirect * occlusion;  // :540
+
+        if (alpha < 1.0f && transp_steps < kMaxTransparencySteps) {  // main.comp:542-547
+          ++transp_steps;
+          color = color + direct * alpha * indirect;
+          indirect = indirect * (1.0f - alpha);
+          next_o = pos + kNormalDelta * ray_dir;
+          next_d = ray_dir;
+        } else {  // main.comp:549-577
+          ++light_steps;
+          color = color + direct * indirect;
+          const Basis basis = orthogonal_matrix(nrm);  // shared by both samplers (:383, :399)
+          float diffuse_pdf, microfacet_pdf;
+          const vec3 diffuse_dir = diffuse_sample(nrm, basis, rng, diffuse_pdf);
+          const vec3 microfacet_dir = microfacet_sample(basis, view, a2, rng, microfacet_pdf);
+          vec3 dir;
+          float c;
+          if (rand_float(rng) < metal) {
+            dir = microfacet_dir;
+            c = metal;
+          } else {
+            dir = diffuse_dir;
+            c = 1.0f - metal;
+          }
+          const float pdf = c * (diffuse_pdf + microfacet_pdf);
+          const float n_dot_l = gmax(dot(nrm, dir), 0.0f);
+          indirect = indirect * (microfacet_brdf(nrm, view, dir, metal, a2, base_color) * n_dot_l / pdf);
+          next_o = shadow_origin;
+          next_d = dir;
+        }
+        path_done = light_steps >= kMaxLightSteps;  // main.comp:512
       }
-      const vec3 c = (radiance * transparency) * xyz(r2) * r2.w / r3.x;     // :427 / :456 / :499-500
-      if (k < n_punctual) punctual = punctual + c;
-      else area = c;
-    }
-    vec3 direct = xyz(h0);          // emission, :536
-    direct = direct + punctual;     // :537
-    direct = direct + area;         // :538
 
-    float4 pb = st.path_b[slot];
-    vec3 color = xyz(pb) + direct * h0.w * xyz(h1);  // :545 / :552
-    if (h1.w != 0.0f) {
-      const float4 h2 = hdr[2];
-      float4 acc = st.accum[slot];
-      finish_sample(color, xyz(h2), mk(f.bg_linear[0], f.bg_linear[1], f.bg_linear[2]), acc, tally);
-      st.accum[slot] = acc;
-      color = splat(0.0f);
+      if (path_done) {  // end of trace() + next stratum of this pixel, or retire the slot (main():597-612)
+        float4 acc = st.accum[slot];
+        finish_sample(color, indirect, bg_linear, acc, tally);
+        st.accum[slot] = acc;
+        ++sample;
+        if (sample < f.sample_end) {
+          uint32_t x, y;
+          slot_to_pixel(f, slot, x, y);
+          camera_ray(f, x, y, sample, rng, next_o, next_d);
+          ++tally.paths;
+          alive = true;
+        }
+        indirect = splat(1.0f);
+        color = splat(0.0f);
+        light_steps = 0;
+        transp_steps = 0;
+      } else {
+        alive = true;
+      }
+
+      if (alive) {
+        st.ray_o[slot] = make_float4(next_o.x, next_o.y, next_o.z, 0.0f);
+        st.ray_d[slot] = make_float4(next_d.x, next_d.y, next_d.z, 0.0f);
+      }
+      st.path_a[slot] = make_float4(indirect.x, indirect.y, indirect.z, ubits(rng));
+      st.path_b[slot] = make_float4(color.x, color.y, color.z, ubits(ctr_pack(light_steps, transp_steps, false, sample)));
     }
-    st.path_b[slot] = make_float4(color.x, color.y, color.z, pb.w);
+
+    // queue compaction (the whole block converges here)
+    const AppendSlots at = block_append2(alive, &st.counters[PT_CNT_QUEUE0 + (parity ^ 1u)], false, nullptr);
+    if (alive) st.queue[parity ^ 1u][at.a] = slot;
   }
-  }
-  flush_tally(tally, st, PT_K_SHADOW);
+  flush_tally(tally, st, PT_K_SHADE);
+  flush_tally(walks, st, PT_K_SHADOW);
 }
 
 // slot order -> pixel order: accum_out = (sum R, sum G, sum B, valid samples)
@@ -970,16 +916,12 @@ void launch_extend(const pt_dev_scene& sc, const pt_dev_state& st, uint32_t pari
 }
 
 void launch_shade(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity,
-                  uint32_t max_entries, hipStream_t s) {
-  hipLaunchKernelGGL(k_shade, dim3(blocks_for(max_entries, 256)), dim3(256), 0, s, sc, f, st, parity);
-}
-
-void launch_shadow(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t max_entries,
-                   uint32_t block, uint32_t max_blocks, hipStream_t s) {
+                  uint32_t max_entries, uint32_t block, uint32_t max_blocks, bool has_lights, hipStream_t s) {
   uint32_t grid = blocks_for(max_entries, block);
   if (grid > max_blocks) grid = max_blocks;
-  if (sc.scene_in_lds) hipLaunchKernelGGL(k_shadow<true>, dim3(grid), dim3(block), trace_lds_bytes(sc, block), s, sc, f, st);
-  else hipLaunchKernelGGL(k_shadow<false>, dim3(grid), dim3(block), trace_lds_bytes(sc, block), s, sc, f, st);
+  const size_t lds = has_lights ? trace_lds_bytes(sc, block) : 0;
+  if (sc.scene_in_lds) hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(block), lds, s, sc, f, st, parity);
+  else hipLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(block), lds, s, sc, f, st, parity);
 }
 
 void launch_finalize(const pt_dev_frame& f, const pt_dev_state& st, float4* accum_out, uint32_t* primary_out, hipStream_t s) {
