@@ -47,7 +47,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
                   if f.endswith(".cpp") and os.path.join(CSRC, "host", f) not in HOST_SRC and f != "main.cpp"]
     srcs = DEVICE_SRC + HOST_SRC + host_extra
     if force or _newer(LIB, srcs):
-        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", *COMMON, *srcs, "-o", LIB, "-lz"]
+        extra = os.environ.get("PT_EXTRA_HIPCC_FLAGS", "").split()
+        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", *COMMON, *extra, *srcs, "-o", os.environ.get("PT_LIB_OUT", LIB), "-lz"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

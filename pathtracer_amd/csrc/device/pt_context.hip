@@ -53,7 +53,8 @@ struct pt_ctx {
   uint32_t out_pixels = 0;
 
   uint32_t band_slots = 0;          // 0 = whole frame in one band
-  uint32_t trace_blocks = 0;        // grid cap of the traversal kernels (persistent workgroups striding the queue)
+  uint32_t trace_blocks = 0;        // grid cap of k_extend (persistent workgroups striding the queue)
+  uint32_t shade_blocks = 0;        // grid cap of k_shade
   uint32_t lds_scene_bytes = 12288; // scenes up to this size (pair records + triangle positions) are staged whole in LDS
   uint32_t* host_counts = nullptr;  // pinned
   hipEvent_t poll_events[2] = {nullptr, nullptr};
@@ -238,8 +239,13 @@ extern "C" pt_ctx* pt_create(int device) {
   ctx->band_slots = kDefaultBandSlots;
   {
     hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->trace_blocks = 8u * static_cast<uint32_t>(prop.multiProcessorCount);
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+      ctx->trace_blocks = 32u * static_cast<uint32_t>(prop.multiProcessorCount);  // measured on cfg2: 8192 > 4096 > 2048
+      ctx->shade_blocks = 8u * static_cast<uint32_t>(prop.multiProcessorCount);   // measured on cfg2: 2048 > 4096 > 8192
+    }
   }
+  if (const char* e = std::getenv("PT_SHADE_BLOCKS")) ctx->shade_blocks = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
+  if (ctx->shade_blocks == 0) ctx->shade_blocks = 2048;
   if (const char* e = std::getenv("PT_TRACE_BLOCKS")) ctx->trace_blocks = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   if (const char* e = std::getenv("PT_LDS_SCENE_BYTES")) ctx->lds_scene_bytes = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   if (ctx->trace_blocks == 0) ctx->trace_blocks = 2048;
@@ -522,7 +528,7 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
       for (uint32_t b = 0; b < kBatch; ++b, ++iter) {
         const uint32_t parity = static_cast<uint32_t>(iter & 1u);
         timed(PT_K_EXTEND, [&] { ptd::launch_extend(sc, st, parity, bound, trace_block, ctx->trace_blocks, stream); });
-        timed(PT_K_SHADE, [&] { ptd::launch_shade(sc, f, st, parity, bound, trace_block, ctx->trace_blocks, n_lights != 0, stream); });
+        timed(PT_K_SHADE, [&] { ptd::launch_shade(sc, f, st, parity, bound, trace_block, ctx->shade_blocks, n_lights != 0, stream); });
       }
       PT_HIP(ctx, hipGetLastError());
       // entries queued for the NEXT iteration; stays intact until that iteration's successor recycles it

@@ -651,8 +651,11 @@ __device__ __forceinline__ float shadow_walk(const pt_dev_scene& sc, const Trace
 // had to evaluate the BRDF, pdf and emitter data of every light sample up front although
 // they only matter for the few samples the walk lets through (measured: DESIGN.md).
 // Persistent workgroups striding the queue, so the LDS scene copy is staged once per block.
+#ifndef PT_SHADE_MIN_WAVES
+#define PT_SHADE_MIN_WAVES 3  // waves per SIMD the register allocator must leave room for (measured: DESIGN.md)
+#endif
 template <bool IN_LDS>
-__global__ __launch_bounds__(256) void k_shade(pt_dev_scene sc, pt_dev_frame f, pt_dev_state st, uint32_t parity) {
+__global__ __launch_bounds__(256, PT_SHADE_MIN_WAVES) void k_shade(pt_dev_scene sc, pt_dev_frame f, pt_dev_state st, uint32_t parity) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
   const uint32_t n = st.counters[PT_CNT_QUEUE0 + parity];
   Tally tally;   // shading work

@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpathtracer_amd.so")
+LIB_PATH = os.environ.get("PT_LIB_PATH", os.path.join(_HERE, "libpathtracer_amd.so"))  # PT_LIB_PATH: experiment builds
 _lib = None
 
 
