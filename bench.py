@@ -54,7 +54,7 @@ def kernel_roofline(name: str, ks: dict, verts: int) -> dict:
     }
 
 
-def cpu_baseline(packed, rp, seconds_hint: float = 12.0) -> dict:
+def cpu_baseline(packed, rp, seconds_hint: float = 15.0) -> dict:
     """The CPU oracle (a port of main.comp, oracle/pt_oracle.c) timed on the host cores on a
     bounded band of rows of the same workload. Reported beside the GPU number; never the target."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -62,12 +62,14 @@ def cpu_baseline(packed, rp, seconds_hint: float = 12.0) -> dict:
     lib = oracle_lib.load()
     cores = min(16, os.cpu_count() or 1)
     h = rp.pc.resolution_y
-    # calibrate on 2 rows, then size the band for ~seconds_hint
+    # warm up (library load, thread start), calibrate on 4 rows, then size the band for ~seconds_hint
     mid = h // 2
+    oracle_lib.render(lib, packed, rp, threads=cores, rows=(mid, min(mid + 1, h)), want_ids=False)
+    cal = min(4, h)
     t0 = time.perf_counter()
-    _, _, _, st = oracle_lib.render(lib, packed, rp, threads=cores, rows=(mid, min(mid + 2, h)), want_ids=False)
+    oracle_lib.render(lib, packed, rp, threads=cores, rows=(mid, min(mid + cal, h)), want_ids=False)
     dt = max(time.perf_counter() - t0, 1e-6)
-    rows = int(max(2, min(h, 2 * seconds_hint / dt)))
+    rows = int(max(cal, min(h, cal * seconds_hint / dt)))
     y0 = max(0, mid - rows // 2)
     y1 = min(h, y0 + rows)
     t0 = time.perf_counter()
@@ -123,7 +125,8 @@ def main() -> None:
     packed = r.pack(scene)
     build_s = time.perf_counter() - t0
     r.upload(packed)
-    seed = (0x5EED0000 + 0x9E3779B9 * rank) & 0xFFFFFFFF  # one decorrelated stream family per rank
+    from pathtracer_amd.distributed import rank_seed
+    seed = rank_seed(0x5EED0000, rank)  # "replicate" split: one decorrelated stream family per rank
     rp = packed.render_params(r.lib, width, height, spp, seed=seed)
     pixels = width * height
 
