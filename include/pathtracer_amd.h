@@ -307,6 +307,36 @@ PT_API int pt_make_push_constants(const pt_render_config* config, const pt_camer
 PT_API void pt_reference_work_group_size(uint32_t resolution_x, uint32_t resolution_y,
                                          uint32_t* local_x, uint32_t* local_y);
 
+/* ------------------------------------------------------------------- front end */
+
+/* load_gltf(path) -> Scene, src/gltf_loader/gltf_loader.h:5 (gltf_loader.cc:487-494): the
+ * loaded scene as borrowed arrays in the scene.h layouts (valid until pt_host_scene_free).
+ * Light arrays include the trailing dummy entry the loader appends (gltf_loader.cc:178-179). */
+typedef struct pt_host_scene pt_host_scene;
+typedef struct pt_host_scene_arrays {
+  const pt_vertex* vertices;                      uint32_t vertex_count;
+  const uint32_t* triangles;                      uint32_t triangle_count;   /* 3 indices each */
+  const pt_material* materials;                   uint32_t material_count;
+  const pt_image* images;                         uint32_t image_count;
+  const pt_sampler* samplers;                     uint32_t sampler_count;
+  const pt_texture* textures;                     uint32_t texture_count;
+  const pt_directional_light* directional_lights; uint32_t directional_light_array_size;
+  const pt_point_light* point_lights;             uint32_t point_light_array_size;
+  pt_camera camera;
+} pt_host_scene_arrays;
+
+PT_API pt_host_scene* pt_host_scene_load(const char* gltf_path); /* NULL on failure: pt_host_last_error() */
+PT_API int pt_host_scene_view(const pt_host_scene* scene, pt_host_scene_arrays* out);
+PT_API void pt_host_scene_free(pt_host_scene* scene);
+PT_API const char* pt_host_last_error(void);
+
+/* stbi_write_png(path, w, h, 4, data, stride), src/main.cc:78-83 */
+PT_API int pt_write_png(const char* path, uint32_t width, uint32_t height, const uint8_t* rgba8, uint32_t stride_bytes);
+/* stb_image decode as tinygltf configures it (4 x 8-bit): PNG only in this build. rgba8_out
+ * may be NULL to query the size. */
+PT_API int pt_decode_image(const uint8_t* bytes, size_t size, uint32_t* width, uint32_t* height,
+                           uint8_t* rgba8_out, size_t out_capacity);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,7 +44,7 @@ def hipcc() -> str:
 
 def build(force: bool = False, verbose: bool = False) -> str:
     host_extra = [os.path.join(CSRC, "host", f) for f in sorted(os.listdir(os.path.join(CSRC, "host")))
-                  if f.endswith(".cpp") and os.path.join(CSRC, "host", f) not in HOST_SRC and f != "main.cpp"]
+                  if f.endswith(".cpp") and os.path.join(CSRC, "host", f) not in HOST_SRC and f not in ("main.cpp", "renderer.cpp")]
     srcs = DEVICE_SRC + HOST_SRC + host_extra
     if force or _newer(LIB, srcs):
         extra = os.environ.get("PT_EXTRA_HIPCC_FLAGS", "").split()
@@ -52,9 +52,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+    # the CLI: the reference's main.cc shape — front end + Renderer binding compiled as plain C++,
+    # the device path reached only through the C ABI of the shared library
     main_cpp = os.path.join(CSRC, "host", "main.cpp")
-    if os.path.exists(main_cpp) and (force or _newer(CLI, [main_cpp, LIB])):
-        cmd = [hipcc(), *COMMON, main_cpp, "-o", CLI, "-L", HERE, "-lpathtracer_amd", "-Wl,-rpath,$ORIGIN"]
+    cli_src = [main_cpp] + [os.path.join(CSRC, "host", f) for f in ("renderer.cpp", "gltf_loader.cpp", "image_io.cpp")]
+    if os.path.exists(main_cpp) and (force or _newer(CLI, cli_src + [LIB])):
+        cmd = ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-Wall", "-I", os.path.join(ROOT, "include"), *cli_src,
+               "-o", CLI, "-L", HERE, "-lpathtracer_amd", "-lz", "-Wl,-rpath,$ORIGIN"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

@@ -1,0 +1,51 @@
+// C++ mirror of the reference's renderer interface (src/renderer/renderer.h:16-55) on top of
+// the C ABI: same names, same argument meaning. A reference maintainer swaps this header for
+// theirs and main.cc keeps compiling.
+#pragma once
+
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "pathtracer_amd.h"
+#include "scene.h"
+
+#define NR_CHANNELS 4
+
+namespace pt {
+
+struct RenderConfig {  // renderer.h:16-20
+  uint32_t resolution_x = 0, resolution_y = 0;
+  uint32_t sample_count = 0;
+  float bg_color[3] = {0, 0, 0};
+};
+
+class Renderer {
+ public:
+  explicit Renderer(uint32_t device_index = static_cast<uint32_t>(-1));  // renderer.h:24
+  ~Renderer();
+  Renderer(const Renderer&) = delete;
+  Renderer& operator=(const Renderer&) = delete;
+
+  // Renderer::render (renderer.h:26-27). Like the reference it permutes scene.triangles
+  // (build_bvh) and appends scene.emissive_triangle_indices; unlike the reference the
+  // returned pixels are owned by this object (valid until the next render), not by a
+  // destroyed RenderJob.
+  std::pair<const unsigned char*, size_t> render(Scene& scene, const RenderConfig& config);
+
+  void set_seed(uint32_t seed) { seed_ = seed; has_seed_ = true; }  // build-only: the reference draws it from std::random_device
+  const pt_stats& stats() const { return stats_; }
+
+ private:
+  pt_ctx* ctx_ = nullptr;
+  std::vector<unsigned char> image_;
+  pt_stats stats_{};
+  uint32_t seed_ = 0;
+  bool has_seed_ = false;
+};
+
+void list_devices();  // renderer.h:55
+
+}  // namespace pt
