@@ -34,7 +34,12 @@ WORKLOADS = {
     "cube512": ("cube_scene", {}, 512, 512, 16, "cfg1: cube, 512x512, 16 spp"),
     "textured1080": ("textured_scene", {"grid": 48}, 1920, 1080, 64, "textured PBR test scene, 1920x1080, 64 spp"),
     "soup1080": ("soup_scene", {"n_tris": 1_000_000}, 1920, 1080, 16, "1M-triangle soup, 1920x1080, 16 spp"),
+    "atrium1080": ("atrium_scene", {"detail": 16, "tex_size": 1024}, 1920, 1080, 256,
+                   "cfg3: generated Sponza-class textured PBR atrium (~253k triangles, 44 1024^2 textures), 1920x1080, 256 spp"),
+    "rocks1080": ("rocks_scene", {"n_tris": 5_000_000}, 1920, 1080, 512,
+                  "cfg4: generated ~5M-triangle rock clusters (deep BVH), 1920x1080, 512 spp (484 effective)"),
 }
+BG = {"atrium1080": (0.5, 0.7, 1.0), "rocks1080": (0.5, 0.7, 1.0), "soup1080": (0.5, 0.7, 1.0)}  # sky; others: README default
 
 
 def kernel_roofline(name: str, ks: dict, verts: int) -> dict:
@@ -127,7 +132,7 @@ def main() -> None:
     r.upload(packed)
     from pathtracer_amd.distributed import rank_seed
     seed = rank_seed(0x5EED0000, rank)  # "replicate" split: one decorrelated stream family per rank
-    rp = packed.render_params(r.lib, width, height, spp, seed=seed)
+    rp = packed.render_params(r.lib, width, height, spp, BG.get(args.workload, (0.239, 0.239, 0.239)), seed)
     pixels = width * height
 
     accum = torch.empty(pixels * 4, dtype=torch.float32, device=dev)
@@ -194,6 +199,8 @@ def main() -> None:
         roof["valu"] = kernels[dominant]["valu"]
         roof["timed_step_ms"] = sd["render_ms"]
         roof["kernel_ms"] = {k: sd[k]["ms"] for k in kernels}
+        if sd["tail"]["launches"]:
+            roof["kernel_ms"]["tail"] = sd["tail"]["ms"]
 
     if rank == 0:
         last = stats.as_dict()

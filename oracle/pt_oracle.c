@@ -600,12 +600,23 @@ static void ray_scene_intersect(shctx* c, const ray_t* ray, isect_t* info) {
 }
 
 /* main.comp:306-332 */
-static float ray_scene_intersect_with_transparency(shctx* c, ray_t ray, isect_t* info) {
+/* target_tri (checker mode only, ORC_NO_HIT = none): the emissive triangle an area-light sample
+ * aims at.  In the all-opaque any-hit mode the HIP path tests that triangle first — if the ray
+ * is accepted by it a hit exists and the result is 0 without walking the tree.  Same result
+ * as the walk by construction (any accepted triangle decides); only the counters shrink. */
+static float ray_scene_intersect_with_transparency(shctx* c, ray_t ray, isect_t* info, uint32_t target_tri) {
   float transparency = 1.0f;
   uint32_t step = 0;
   if (c->any_hit_shadows) { /* every surface has alpha == 1: the first closest hit returns 0 (main.comp:325) */
     info->t = ORC_INFINITY;
     info->tri_idx = ORC_NO_HIT;
+    if (target_tri != ORC_NO_HIT) {
+      ray_triangle_intersect(c, &ray, target_tri, info);
+      if (info->tri_idx != ORC_NO_HIT) {
+        ++c->st.rays;
+        return 0.0f;
+      }
+    }
     ray_scene_intersect_ex(c, &ray, info, 1);
     return info->tri_idx == ORC_NO_HIT ? 1.0f : 0.0f;
   }
@@ -728,7 +739,7 @@ static v3 sample_punctual_light(shctx* c, v3 n, v3 v, v3 pos, float metal, float
     ray_t ray;
     ray.origin = vadd(pos, vscale(n, ORC_NORMAL_DELTA));
     ray.dir = l;
-    float transparency = ray_scene_intersect_with_transparency(c, ray, &info);
+    float transparency = ray_scene_intersect_with_transparency(c, ray, &info, ORC_NO_HIT);
     if (transparency == 0.0f) continue;
 
     float n_dot_l = gmax(vdot(n, l), 0.0f);
@@ -750,7 +761,7 @@ static v3 sample_punctual_light(shctx* c, v3 n, v3 v, v3 pos, float metal, float
     ray_t ray;
     ray.origin = vadd(pos, vscale(n, ORC_NORMAL_DELTA));
     ray.dir = l;
-    float transparency = ray_scene_intersect_with_transparency(c, ray, &info);
+    float transparency = ray_scene_intersect_with_transparency(c, ray, &info, ORC_NO_HIT);
     if (transparency == 0.0f) continue;
     float correction = ORC_NORMAL_DELTA / vdot(l, n);
     if (info.tri_idx != ORC_NO_HIT && info.t + correction < vlength(vsub(pos, sample_pos))) continue;
@@ -792,7 +803,7 @@ static v3 sample_area_light(shctx* c, v3 n, v3 v, v3 pos, float metal, float a2,
   ray_t ray;
   ray.origin = vadd(pos, vscale(n, ORC_NORMAL_DELTA));
   ray.dir = l;
-  float transparency = ray_scene_intersect_with_transparency(c, ray, &info);
+  float transparency = ray_scene_intersect_with_transparency(c, ray, &info, tri_idx);
   if (transparency == 0.0f) return vs(0.0f);
   float correction = ORC_NORMAL_DELTA / vdot(l, n);
   if (info.tri_idx != ORC_NO_HIT && info.t + correction < vlength(vsub(pos, tri_pos))) return vs(0.0f);

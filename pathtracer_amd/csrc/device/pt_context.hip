@@ -55,6 +55,7 @@ struct pt_ctx {
   uint32_t band_slots = 0;          // 0 = whole frame in one band
   uint32_t trace_blocks = 0;        // grid cap of k_extend (persistent workgroups striding the queue)
   uint32_t shade_blocks = 0;        // grid cap of k_shade
+  uint32_t tail_entries = 262144;   // queue length below which the rest of the frame runs in one k_tail launch (0 = never)
   uint32_t lds_scene_bytes = 12288; // scenes up to this size (pair records + triangle positions) are staged whole in LDS
   uint32_t* host_counts = nullptr;  // pinned
   hipEvent_t poll_events[2] = {nullptr, nullptr};
@@ -250,6 +251,7 @@ extern "C" pt_ctx* pt_create(int device) {
   if (const char* e = std::getenv("PT_LDS_SCENE_BYTES")) ctx->lds_scene_bytes = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   if (ctx->trace_blocks == 0) ctx->trace_blocks = 2048;
   if (ctx->lds_scene_bytes > 32768) ctx->lds_scene_bytes = 32768;
+  if (const char* e = std::getenv("PT_TAIL_ENTRIES")) ctx->tail_entries = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   if (const char* e = std::getenv("PT_BAND_SLOTS")) ctx->band_slots = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   bool ok = hipSetDevice(device) == hipSuccess &&
             hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
@@ -488,7 +490,7 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
   const bool time_kernels = (p->flags & PT_FLAG_TIME_KERNELS) != 0;
   size_t ev_used = 0;
   std::vector<std::pair<size_t, int>> ev_kind;  // index of the start event, kernel id
-  uint64_t launches[PT_K_COUNT] = {0, 0, 0, 0};
+  uint64_t launches[PT_K_COUNT + 1] = {0, 0, 0, 0, 0};
 
   auto timed = [&](int kind, auto&& launch) {
     ++launches[kind];
@@ -543,6 +545,14 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
       }
       have_prev = true;
       poll ^= 1;
+      if (!drained && bound <= ctx->tail_entries) {
+        // short queue: every remaining vertex of every queued slot in one launch (k_tail)
+        const uint32_t parity = static_cast<uint32_t>(iter & 1u);
+        const uint32_t max_vertices = static_cast<uint32_t>(max_iters > 0xFFFFFFFFull ? 0xFFFFFFFFull : max_iters);
+        timed(PT_K_TAIL, [&] { ptd::launch_tail(sc, f, st, parity, bound, trace_block, max_vertices, stream); });
+        PT_HIP(ctx, hipGetLastError());
+        drained = true;
+      }
     }
     if (!drained) {
       PT_HIP(ctx, hipEventSynchronize(ctx->poll_events[poll ^ 1]));
@@ -577,7 +587,8 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
     stats_out->shaded_vertices = total(PT_ST_VERTS);
     stats_out->nan_samples = total(PT_ST_NANS);
     stats_out->iterations = iter;
-    pt_kernel_stats* per[PT_K_COUNT] = {nullptr, &stats_out->extend, &stats_out->shade, &stats_out->shadow};
+    pt_kernel_stats* per[PT_K_COUNT + 1] = {nullptr, &stats_out->extend, &stats_out->shade, &stats_out->shadow, &stats_out->tail};
+    stats_out->tail.launches = launches[PT_K_TAIL];
     for (int k = PT_K_EXTEND; k < PT_K_COUNT; ++k) {
       per[k]->launches = launches[k];
       per[k]->rays = h[k][PT_ST_RAYS];

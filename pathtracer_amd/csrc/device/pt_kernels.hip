@@ -243,6 +243,14 @@ __device__ __forceinline__ void ray_triangle(const Tracer& tr, vec3 o, vec3 d, u
 // ANY_HIT (shadow rays of provably all-opaque scenes): the traversal ends at the first
 // accepted triangle. The order is unchanged, so whether a hit exists is decided exactly as
 // by the full closest-hit search; h then holds *a* hit, not the closest.
+// Two loop shapes, same per-ray order of visits and tests:
+//  - LDS-resident scenes (VALU-issue bound) run "while-while": a lane keeps descending inner
+//    nodes until it stands on a leaf, and only then do the lanes of the wave that stand on
+//    leaves run the triangle tests together, so the ~70-instruction triangle arm is not
+//    executed on nearly every trip for the one or two lanes that need it (+3 % on cfg2).
+//  - scenes read from global memory (latency bound) keep inner and leaf handling as the two
+//    arms of one trip, so every lane issues its next fetch every trip (while-while was
+//    13 % slower on the 1 M-triangle soup: lanes parked on a leaf have no load in flight).
 template <bool IN_LDS, bool ANY_HIT>
 __device__ __forceinline__ void traverse(const Tracer& tr, vec3 o, vec3 d, Hit& h, Tally& tally) {
   ++tally.rays;
@@ -250,42 +258,63 @@ __device__ __forceinline__ void traverse(const Tracer& tr, vec3 o, vec3 d, Hit& 
   uint32_t sp = 0;
   uint32_t ref = tr.root_ref;  // root: never box-tested (Q13)
   uint32_t cnt = tr.root_cnt;
-  for (;;) {
-    if (cnt > 0) {
-      if (ANY_HIT) {
-        for (uint32_t i = 0; i < cnt; ++i) {
-          ++tally.tests;
-          ray_triangle<IN_LDS>(tr, o, d, ref + i, h);
-          if (h.tri != kNoHit) return;
-        }
-      } else {
-        tally.tests += cnt;
-        for (uint32_t i = 0; i < cnt; ++i) ray_triangle<IN_LDS>(tr, o, d, ref + i, h);
-      }
-    } else {
-      ++tally.visits;
-      const float4 l0 = fetch16<IN_LDS>(tr.pairs, 4 * ref), l1 = fetch16<IN_LDS>(tr.pairs, 4 * ref + 1);
-      const float4 r0 = fetch16<IN_LDS>(tr.pairs, 4 * ref + 2), r1 = fetch16<IN_LDS>(tr.pairs, 4 * ref + 3);
-      float dist_l, dist_r;
-      bool hit_l, hit_r;
-      ray_box_pair(o, inv, l0, l1, r0, r1, h.t, hit_l, hit_r, dist_l, dist_r);
-      if (hit_l || hit_r) {
-        const bool go_left = hit_l && (!hit_r || dist_l < dist_r);  // equal distances: right is near (Q14)
-        if (hit_l && hit_r) {
-          tr.stack[sp * tr.stride] = (ref << 1) | (go_left ? 1u : 0u);  // the far side
-          ++sp;
-        }
-        ref = go_left ? fbits(l0.w) : fbits(r0.w);
-        cnt = go_left ? fbits(l1.w) : fbits(r1.w);
-        continue;
-      }
+  bool live = true;
+  // pop the next deferred child into (ref, cnt), or end the traversal
+  auto pop = [&]() {
+    if (sp == 0) {
+      live = false;
+      return;
     }
-    if (sp == 0) break;
     --sp;
     const uint32_t e = tr.stack[sp * tr.stride];
     const uint32_t word = 4u * (e >> 1) + 2u * (e & 1u);
     ref = fbits(fetch16<IN_LDS>(tr.pairs, word).w);
     cnt = fbits(fetch16<IN_LDS>(tr.pairs, word + 1u).w);
+  };
+  auto inner = [&]() {
+    ++tally.visits;
+    const float4 l0 = fetch16<IN_LDS>(tr.pairs, 4 * ref), l1 = fetch16<IN_LDS>(tr.pairs, 4 * ref + 1);
+    const float4 r0 = fetch16<IN_LDS>(tr.pairs, 4 * ref + 2), r1 = fetch16<IN_LDS>(tr.pairs, 4 * ref + 3);
+    float dist_l, dist_r;
+    bool hit_l, hit_r;
+    ray_box_pair(o, inv, l0, l1, r0, r1, h.t, hit_l, hit_r, dist_l, dist_r);
+    if (hit_l || hit_r) {
+      const bool go_left = hit_l && (!hit_r || dist_l < dist_r);  // equal distances: right is near (Q14)
+      if (hit_l && hit_r) {
+        tr.stack[sp * tr.stride] = (ref << 1) | (go_left ? 1u : 0u);  // the far side
+        ++sp;
+      }
+      ref = go_left ? fbits(l0.w) : fbits(r0.w);
+      cnt = go_left ? fbits(l1.w) : fbits(r1.w);
+    } else {
+      pop();
+    }
+  };
+  auto leaf = [&]() -> bool {  // true: an any-hit traversal is decided
+    if (ANY_HIT) {
+      for (uint32_t i = 0; i < cnt; ++i) {
+        ++tally.tests;
+        ray_triangle<IN_LDS>(tr, o, d, ref + i, h);
+        if (h.tri != kNoHit) return true;
+      }
+    } else {
+      tally.tests += cnt;
+      for (uint32_t i = 0; i < cnt; ++i) ray_triangle<IN_LDS>(tr, o, d, ref + i, h);
+    }
+    pop();
+    return false;
+  };
+  if (IN_LDS) {
+    while (live) {
+      while (live && cnt == 0) inner();
+      while (live && cnt > 0)
+        if (leaf()) return;
+    }
+  } else {
+    while (live) {
+      if (cnt == 0) inner();
+      else if (leaf()) return;
+    }
   }
 }
 
@@ -613,11 +642,14 @@ __global__ __launch_bounds__(256) void k_extend(pt_dev_scene sc, pt_dev_state st
 
 // ray_scene_intersect_with_transparency, main.comp:306-332. Returns the transparency and
 // leaves the last traversal's result in h.
-template <bool IN_LDS>
+template <bool IN_LDS, bool ALL_OPAQUE>
 __device__ __forceinline__ float shadow_walk(const pt_dev_scene& sc, const Tracer& tr, vec3 origin, vec3 dir, Hit& h,
                                              Tally& tally) {
   float transparency = 1.0f;
-  if (sc.all_opaque) {  // every closest hit has alpha == 1 and returns 0 (main.comp:325): any hit decides
+#ifdef PT_EXP_NO_SHADOW  // timing experiment only: skip the walk (wrong images)
+  return transparency;
+#endif
+  if (ALL_OPAQUE) {  // every closest hit has alpha == 1 and returns 0 (main.comp:325): any hit decides
     h.t = kInfinity;
     h.tri = kNoHit;
     traverse<IN_LDS, true>(tr, origin, dir, h, tally);
@@ -643,18 +675,227 @@ __device__ __forceinline__ float shadow_walk(const pt_dev_scene& sc, const Trace
   return transparency;
 }
 
-// trace() loop body (main.comp:517-577) for every extended ray: miss handling, interpolation,
-// material, light sampling WITH its shadow walks, BSDF sampling, sample bookkeeping and
-// path regeneration (main():597-612), then compaction of the survivors into the next queue.
+// One path vertex: the trace() loop body (main.comp:517-577) for an extended ray — miss
+// handling, interpolation, material, light sampling WITH its shadow walks, BSDF sampling —
+// then the sample bookkeeping and path regeneration of main():597-612. Returns whether the
+// slot continues with the ray (next_o, next_d). Shared by k_shade (one vertex per launch) and
+// k_tail (a slot's remaining vertices in one launch).
 // The shadow walks run here rather than in a kernel of their own: a separate shadow kernel
 // needed a 112-byte request per vertex and light written and read back through HBM, and
 // had to evaluate the BRDF, pdf and emitter data of every light sample up front although
 // they only matter for the few samples the walk lets through (measured: DESIGN.md).
-// Persistent workgroups striding the queue, so the LDS scene copy is staged once per block.
+struct PathRegs {
+  vec3 indirect, color;
+  uint32_t rng, light_steps, transp_steps, sample;
+};
+
+template <bool IN_LDS, bool ALL_OPAQUE>
+__device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st,
+                                             const Tracer& tr, uint32_t n_lights, vec3 bg_linear, uint32_t slot,
+                                             const Hit& hit, vec3 ray_dir, PathRegs& p, vec3& next_o, vec3& next_d,
+                                             Tally& tally, Tally& walks) {
+  vec3 indirect = p.indirect, color = p.color;
+  uint32_t rng = p.rng, light_steps = p.light_steps, transp_steps = p.transp_steps, sample = p.sample;
+  bool alive = false;
+  bool path_done = false;  // the sample ends at this vertex
+
+  if (hit.tri == kNoHit) {  // main.comp:517 -> :580
+    path_done = true;
+  } else {
+    const vec3 wuv = mk(1.0f - hit.u - hit.v, hit.u, hit.v);
+    vec3 pos, nrm;
+    float tu, tv;
+    uint32_t mat_idx;
+    interpolate_pos_uv(sc, hit.tri, wuv, pos, tu, tv, mat_idx, &nrm, tally);
+    if (dot(nrm, ray_dir) > 0.0f) nrm = nrm * -1.0f;  // main.comp:524
+
+    // get_material_data, main.comp:242-259
+    const Material m = load_material(sc.materials, mat_idx);
+    const float4 bc = sample_texture(sc, m.base_tex, tu, tv, tally);
+    const vec3 base_color = mk(m.base_color.x, m.base_color.y, m.base_color.z) * decode_srgb(m.base_tex, bc);
+    const float alpha = m.base_color.w * bc.w;
+    const float4 mr = sample_texture(sc, m.mr_tex, tu, tv, tally);
+    const float metal = m.metallic * mr.z;
+    const float roughness = m.roughness * mr.y;
+    const float4 em = sample_texture(sc, m.emissive_tex, tu, tv, tally);
+    const vec3 emission = m.emissive * decode_srgb(m.emissive_tex, em);
+    const float4 oc = sample_texture(sc, m.occlusion_tex, tu, tv, tally);
+    const float occlusion = 1.0f + m.occlusion_strength * (oc.x - 1.0f);
+    const float a = roughness * roughness;
+    const float a2 = a * a;
+    ++tally.verts;
+
+    const vec3 view = -ray_dir;
+    const vec3 shadow_origin = pos + kNormalDelta * nrm;
+
+    // sample_punctual_light (main.comp:409-460) and sample_area_light (:464-501) as ONE loop
+    // over the vertex's light samples — directional lights, point lights, then the area
+    // sample, i.e. the reference's order of RNG draws and of the `+=` into `punctual` — so
+    // that the kernel holds a single copy of the shadow walk (three inlined copies were
+    // 16 k instructions and 168 VGPRs).
+    vec3 punctual = splat(0.0f);
+    vec3 area_light = splat(0.0f);
+    const uint32_t n_dir = sc.directional_light_count, n_punctual = n_dir + sc.point_light_count;
+    for (uint32_t j = 0; j < n_lights; ++j) {
+      vec3 l, sample_pos = splat(0.0f), sample_dir = splat(0.0f);
+      float4 l0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+      float dist2 = 0.0f;
+      uint32_t etri = 0;
+      vec3 ewuv = splat(0.0f);
+      float4 q0 = l0, q1 = l0, q2 = l0;
+      const uint32_t kind = j < n_dir ? 0u : (j < n_punctual ? 1u : 2u);
+      if (kind == 0u) {
+        l0 = sc.directional_lights[2 * j];
+        l = -xyz(sc.directional_lights[2 * j + 1]);
+      } else if (kind == 1u) {
+        const uint32_t i = j - n_dir;
+        l0 = sc.point_lights[2 * i];
+        const vec3 lpos = xyz(sc.point_lights[2 * i + 1]);
+        sample_dir = uniform_hemisphere_sampling(normalize(pos - lpos), rng);
+        sample_pos = lpos + sample_dir * kPointLightRadius;
+        l = sample_pos - pos;
+        dist2 = dot(l, l);
+        l = normalize(l);
+      } else {
+        const uint32_t count = f.pc.emissive_triangle_count;
+        uint32_t pick = static_cast<uint32_t>(rand_float(rng) * static_cast<float>(count));
+        if (pick > count - 1) pick = count - 1;  // Q3: rand_float may be exactly 1.0
+        etri = sc.emissive_triangles[pick];
+        float su = rand_float(rng), sv = rand_float(rng);  // sample_triangle, main.comp:158-165
+        if (su + sv > 1.0f) {
+          su = 1.0f - su;
+          sv = 1.0f - sv;
+        }
+        ewuv = mk(1.0f - su - sv, su, sv);
+        // get_interpolated_data of the emitter; its normal, uv and material are only needed
+        // if the walk lets the sample through, so only the position is formed here
+        ++tally.hits;
+        q0 = sc.tri_pos[3 * static_cast<size_t>(etri)];
+        q1 = sc.tri_pos[3 * static_cast<size_t>(etri) + 1];
+        q2 = sc.tri_pos[3 * static_cast<size_t>(etri) + 2];
+        sample_pos = mat3_mul(xyz(q0), xyz(q1), xyz(q2), ewuv);
+        l = sample_pos - pos;
+        dist2 = dot(l, l);
+        l = normalize(l);
+      }
+
+      Hit sh{kInfinity, 0.0f, 0.0f, kNoHit};
+      if (ALL_OPAQUE && kind == 2u) {
+        // Any accepted triangle along the ray decides an all-opaque shadow query (Q5), and an
+        // area sample aims at a known triangle: test that one first. Most samples seen from
+        // its front are accepted by it and never walk the tree (the oracle's checker mode
+        // mirrors the shortcut, so the visit/test counters still compare equal).
+        ++walks.tests;
+        ray_triangle<IN_LDS>(tr, shadow_origin, l, etri, sh);
+        if (sh.tri != kNoHit) {
+          ++walks.rays;
+          continue;
+        }
+      }
+      const float transparency = shadow_walk<IN_LDS, ALL_OPAQUE>(sc, tr, shadow_origin, l, sh, walks);
+      if (transparency == 0.0f) continue;
+      if (kind != 0u) {
+        const float correction = kNormalDelta / dot(l, nrm);
+        if (sh.tri != kNoHit && sh.t + correction < length(pos - sample_pos)) continue;
+      }
+      if (kind == 0u) {
+        const float n_dot_l = gmax(dot(nrm, l), 0.0f);
+        const vec3 radiance = xyz(l0) * l0.w * transparency;
+        punctual = punctual + radiance * microfacet_brdf(nrm, view, l, metal, a2, base_color) * n_dot_l;
+      } else if (kind == 1u) {
+        const vec3 radiance = xyz(l0) * l0.w / kLightArea / kFourPi * transparency;
+        const float cos_theta0 = dot(sample_dir, -l);
+        const float pdf = dist2 / (cos_theta0 * kLightArea);
+        const float n_dot_l = __builtin_fabsf(dot(nrm, l));
+        punctual = punctual + radiance * microfacet_brdf(nrm, view, l, metal, a2, base_color) * n_dot_l / pdf;
+      } else {
+        const TriAttr at = load_attr(sc.tri_attr, etri);
+        vec3 tri_n = normalize(mat3_mul(at.n0, at.n1, at.n2, ewuv));
+        const float eu = at.u0 * ewuv.x + at.u1 * ewuv.y + at.u2 * ewuv.z;
+        const float ev = at.v0 * ewuv.x + at.v1 * ewuv.y + at.v2 * ewuv.z;
+        if (dot(l, tri_n) > 0.0f) tri_n = tri_n * -1.0f;
+        const float area = length(cross(xyz(q1) - xyz(q0), xyz(q2) - xyz(q0))) / 2.0f;
+        const float cos_theta0 = dot(tri_n, -l);
+        const float pdf = dist2 / (cos_theta0 * area) / static_cast<float>(f.pc.emissive_triangle_count);
+        const float n_dot_l = __builtin_fabsf(dot(nrm, l));
+        const Material emat = load_material(sc.materials, at.mat);
+        const float4 et = sample_texture(sc, emat.emissive_tex, eu, ev, tally);
+        const vec3 e_emission = emat.emissive * decode_srgb(emat.emissive_tex, et) * transparency;
+        area_light = e_emission * microfacet_brdf(nrm, view, l, metal, a2, base_color) * n_dot_l / pdf;
+      }
+    }
+
+    vec3 direct = emission;        // main.comp:536
+    direct = direct + punctual;    // :537
+    direct = direct + area_light;  // :538
+    indirect = indirect * occlusion;  // :540
+
+    if (alpha < 1.0f && transp_steps < kMaxTransparencySteps) {  // main.comp:542-547
+      ++transp_steps;
+      color = color + direct * alpha * indirect;
+      indirect = indirect * (1.0f - alpha);
+      next_o = pos + kNormalDelta * ray_dir;
+      next_d = ray_dir;
+    } else {  // main.comp:549-577
+      ++light_steps;
+      color = color + direct * indirect;
+      const Basis basis = orthogonal_matrix(nrm);  // shared by both samplers (:383, :399)
+      float diffuse_pdf, microfacet_pdf;
+      const vec3 diffuse_dir = diffuse_sample(nrm, basis, rng, diffuse_pdf);
+      const vec3 microfacet_dir = microfacet_sample(basis, view, a2, rng, microfacet_pdf);
+      vec3 dir;
+      float c;
+      if (rand_float(rng) < metal) {
+        dir = microfacet_dir;
+        c = metal;
+      } else {
+        dir = diffuse_dir;
+        c = 1.0f - metal;
+      }
+      const float pdf = c * (diffuse_pdf + microfacet_pdf);
+      const float n_dot_l = gmax(dot(nrm, dir), 0.0f);
+      indirect = indirect * (microfacet_brdf(nrm, view, dir, metal, a2, base_color) * n_dot_l / pdf);
+      next_o = shadow_origin;
+      next_d = dir;
+    }
+    path_done = light_steps >= kMaxLightSteps;  // main.comp:512
+  }
+
+  if (path_done) {  // end of trace() + next stratum of this pixel, or retire the slot (main():597-612)
+    float4 acc = st.accum[slot];
+    finish_sample(color, indirect, bg_linear, acc, tally);
+    st.accum[slot] = acc;
+    ++sample;
+    if (sample < f.sample_end) {
+      uint32_t x, y;
+      slot_to_pixel(f, slot, x, y);
+      camera_ray(f, x, y, sample, rng, next_o, next_d);
+      ++tally.paths;
+      alive = true;
+    }
+    indirect = splat(1.0f);
+    color = splat(0.0f);
+    light_steps = 0;
+    transp_steps = 0;
+  } else {
+    alive = true;
+  }
+
+  p.indirect = indirect;
+  p.color = color;
+  p.rng = rng;
+  p.light_steps = light_steps;
+  p.transp_steps = transp_steps;
+  p.sample = sample;
+  return alive;
+}
+
 #ifndef PT_SHADE_MIN_WAVES
 #define PT_SHADE_MIN_WAVES 3  // waves per SIMD the register allocator must leave room for (measured: DESIGN.md)
 #endif
-template <bool IN_LDS>
+// shade_vertex for every extended ray, then compaction of the survivors into the next queue.
+// Persistent workgroups striding the queue, so the LDS scene copy is staged once per block.
+template <bool IN_LDS, bool ALL_OPAQUE>
 __global__ __launch_bounds__(256, PT_SHADE_MIN_WAVES) void k_shade(pt_dev_scene sc, pt_dev_frame f, pt_dev_state st, uint32_t parity) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
   const uint32_t n = st.counters[PT_CNT_QUEUE0 + parity];
@@ -676,192 +917,71 @@ __global__ __launch_bounds__(256, PT_SHADE_MIN_WAVES) void k_shade(pt_dev_scene 
       const uint4 hw = st.hit[slot];
       const float4 pa = st.path_a[slot];
       const float4 pb = st.path_b[slot];
-      vec3 indirect = xyz(pa);
-      uint32_t rng = fbits(pa.w);
-      vec3 color = xyz(pb);
       const uint32_t ctr = fbits(pb.w);
-      uint32_t light_steps = ctr_light(ctr), transp_steps = ctr_transp(ctr), sample = ctr_sample(ctr);
-
+      PathRegs p{xyz(pa), xyz(pb), fbits(pa.w), ctr_light(ctr), ctr_transp(ctr), ctr_sample(ctr)};
       if (ctr_primary(ctr)) st.primary_id[slot] = hw.x;
-
-      bool path_done = false;  // the sample ends at this vertex
+      const Hit hit{ubits(hw.w), ubits(hw.y), ubits(hw.z), hw.x};
+      vec3 ray_dir = mk(0, 0, 0);
+      if (hw.x != kNoHit) ray_dir = xyz(st.ray_d[slot]);
       vec3 next_o = mk(0, 0, 0), next_d = mk(0, 0, 0);
-
-      if (hw.x == kNoHit) {  // main.comp:517 -> :580
-        path_done = true;
-      } else {
-        const float4 d4 = st.ray_d[slot];
-        const vec3 ray_dir = xyz(d4);
-        const float hu = ubits(hw.y), hv = ubits(hw.z);
-        const vec3 wuv = mk(1.0f - hu - hv, hu, hv);
-        vec3 pos, nrm;
-        float tu, tv;
-        uint32_t mat_idx;
-        interpolate_pos_uv(sc, hw.x, wuv, pos, tu, tv, mat_idx, &nrm, tally);
-        if (dot(nrm, ray_dir) > 0.0f) nrm = nrm * -1.0f;  // main.comp:524
-
-        // get_material_data, main.comp:242-259
-        const Material m = load_material(sc.materials, mat_idx);
-        const float4 bc = sample_texture(sc, m.base_tex, tu, tv, tally);
-        const vec3 base_color = mk(m.base_color.x, m.base_color.y, m.base_color.z) * decode_srgb(m.base_tex, bc);
-        const float alpha = m.base_color.w * bc.w;
-        const float4 mr = sample_texture(sc, m.mr_tex, tu, tv, tally);
-        const float metal = m.metallic * mr.z;
-        const float roughness = m.roughness * mr.y;
-        const float4 em = sample_texture(sc, m.emissive_tex, tu, tv, tally);
-        const vec3 emission = m.emissive * decode_srgb(m.emissive_tex, em);
-        const float4 oc = sample_texture(sc, m.occlusion_tex, tu, tv, tally);
-        const float occlusion = 1.0f + m.occlusion_strength * (oc.x - 1.0f);
-        const float a = roughness * roughness;
-        const float a2 = a * a;
-        ++tally.verts;
-
-        const vec3 view = -ray_dir;
-        const vec3 shadow_origin = pos + kNormalDelta * nrm;
-
-        // sample_punctual_light, main.comp:409-460
-        vec3 punctual = splat(0.0f);
-        for (uint32_t i = 0; i < sc.directional_light_count; ++i) {
-          const float4 l0 = sc.directional_lights[2 * i], l1 = sc.directional_lights[2 * i + 1];
-          const vec3 l = -xyz(l1);
-          Hit sh{kInfinity, 0.0f, 0.0f, kNoHit};
-          const float transparency = shadow_walk<IN_LDS>(sc, tr, shadow_origin, l, sh, walks);
-          if (transparency == 0.0f) continue;
-          const float n_dot_l = gmax(dot(nrm, l), 0.0f);
-          const vec3 radiance = xyz(l0) * l0.w * transparency;
-          punctual = punctual + radiance * microfacet_brdf(nrm, view, l, metal, a2, base_color) * n_dot_l;
-        }
-        for (uint32_t i = 0; i < sc.point_light_count; ++i) {
-          const float4 l0 = sc.point_lights[2 * i], l1 = sc.point_lights[2 * i + 1];
-          const vec3 lpos = xyz(l1);
-          const vec3 sample_dir = uniform_hemisphere_sampling(normalize(pos - lpos), rng);
-          const vec3 sample_pos = lpos + sample_dir * kPointLightRadius;
-          vec3 l = sample_pos - pos;
-          const float dist2 = dot(l, l);
-          l = normalize(l);
-          Hit sh{kInfinity, 0.0f, 0.0f, kNoHit};
-          const float transparency = shadow_walk<IN_LDS>(sc, tr, shadow_origin, l, sh, walks);
-          if (transparency == 0.0f) continue;
-          const float correction = kNormalDelta / dot(l, nrm);
-          if (sh.tri != kNoHit && sh.t + correction < length(pos - sample_pos)) continue;
-          const vec3 radiance = xyz(l0) * l0.w / kLightArea / kFourPi * transparency;
-          const float cos_theta0 = dot(sample_dir, -l);
-          const float pdf = dist2 / (cos_theta0 * kLightArea);
-          const float n_dot_l = __builtin_fabsf(dot(nrm, l));
-          punctual = punctual + radiance * microfacet_brdf(nrm, view, l, metal, a2, base_color) * n_dot_l / pdf;
-        }
-
-        // sample_area_light, main.comp:464-501
-        vec3 area_light = splat(0.0f);
-        if (f.pc.emissive_triangle_count) {
-          const uint32_t count = f.pc.emissive_triangle_count;
-          uint32_t pick = static_cast<uint32_t>(rand_float(rng) * static_cast<float>(count));
-          if (pick > count - 1) pick = count - 1;  // Q3: rand_float may be exactly 1.0
-          const uint32_t etri = sc.emissive_triangles[pick];
-          float su = rand_float(rng), sv = rand_float(rng);  // sample_triangle, main.comp:158-165
-          if (su + sv > 1.0f) {
-            su = 1.0f - su;
-            sv = 1.0f - sv;
-          }
-          const vec3 ewuv = mk(1.0f - su - sv, su, sv);
-          // get_interpolated_data of the emitter; its normal, uv and material are only needed
-          // if the walk lets the sample through, so only the position is formed here
-          ++tally.hits;
-          const float4 q0 = sc.tri_pos[3 * static_cast<size_t>(etri)];
-          const float4 q1 = sc.tri_pos[3 * static_cast<size_t>(etri) + 1];
-          const float4 q2 = sc.tri_pos[3 * static_cast<size_t>(etri) + 2];
-          const vec3 tri_pos = mat3_mul(xyz(q0), xyz(q1), xyz(q2), ewuv);
-          vec3 l = tri_pos - pos;
-          const float dist2 = dot(l, l);
-          l = normalize(l);
-          Hit sh{kInfinity, 0.0f, 0.0f, kNoHit};
-          const float transparency = shadow_walk<IN_LDS>(sc, tr, shadow_origin, l, sh, walks);
-          const float correction = kNormalDelta / dot(l, nrm);
-          if (transparency != 0.0f && !(sh.tri != kNoHit && sh.t + correction < length(pos - tri_pos))) {
-            const TriAttr at = load_attr(sc.tri_attr, etri);
-            vec3 tri_n = normalize(mat3_mul(at.n0, at.n1, at.n2, ewuv));
-            const float eu = at.u0 * ewuv.x + at.u1 * ewuv.y + at.u2 * ewuv.z;
-            const float ev = at.v0 * ewuv.x + at.v1 * ewuv.y + at.v2 * ewuv.z;
-            if (dot(l, tri_n) > 0.0f) tri_n = tri_n * -1.0f;
-            const float area = length(cross(xyz(q1) - xyz(q0), xyz(q2) - xyz(q0))) / 2.0f;
-            const float cos_theta0 = dot(tri_n, -l);
-            const float pdf = dist2 / (cos_theta0 * area) / static_cast<float>(count);
-            const float n_dot_l = __builtin_fabsf(dot(nrm, l));
-            const Material emat = load_material(sc.materials, at.mat);
-            const float4 et = sample_texture(sc, emat.emissive_tex, eu, ev, tally);
-            const vec3 e_emission = emat.emissive * decode_srgb(emat.emissive_tex, et) * transparency;
-            area_light = e_emission * microfacet_brdf(nrm, view, l, metal, a2, base_color) * n_dot_l / pdf;
-          }
-        }
-
-        vec3 direct = emission;        // main.comp:536
-        direct = direct + punctual;    // :537
-        direct = direct + area_light;  // :538
-        indirect = indirect * occlusion;  // :540
-
-        if (alpha < 1.0f && transp_steps < kMaxTransparencySteps) {  // main.comp:542-547
-          ++transp_steps;
-          color = color + direct * alpha * indirect;
-          indirect = indirect * (1.0f - alpha);
-          next_o = pos + kNormalDelta * ray_dir;
-          next_d = ray_dir;
-        } else {  // main.comp:549-577
-          ++light_steps;
-          color = color + direct * indirect;
-          const Basis basis = orthogonal_matrix(nrm);  // shared by both samplers (:383, :399)
-          float diffuse_pdf, microfacet_pdf;
-          const vec3 diffuse_dir = diffuse_sample(nrm, basis, rng, diffuse_pdf);
-          const vec3 microfacet_dir = microfacet_sample(basis, view, a2, rng, microfacet_pdf);
-          vec3 dir;
-          float c;
-          if (rand_float(rng) < metal) {
-            dir = microfacet_dir;
-            c = metal;
-          } else {
-            dir = diffuse_dir;
-            c = 1.0f - metal;
-          }
-          const float pdf = c * (diffuse_pdf + microfacet_pdf);
-          const float n_dot_l = gmax(dot(nrm, dir), 0.0f);
-          indirect = indirect * (microfacet_brdf(nrm, view, dir, metal, a2, base_color) * n_dot_l / pdf);
-          next_o = shadow_origin;
-          next_d = dir;
-        }
-        path_done = light_steps >= kMaxLightSteps;  // main.comp:512
-      }
-
-      if (path_done) {  // end of trace() + next stratum of this pixel, or retire the slot (main():597-612)
-        float4 acc = st.accum[slot];
-        finish_sample(color, indirect, bg_linear, acc, tally);
-        st.accum[slot] = acc;
-        ++sample;
-        if (sample < f.sample_end) {
-          uint32_t x, y;
-          slot_to_pixel(f, slot, x, y);
-          camera_ray(f, x, y, sample, rng, next_o, next_d);
-          ++tally.paths;
-          alive = true;
-        }
-        indirect = splat(1.0f);
-        color = splat(0.0f);
-        light_steps = 0;
-        transp_steps = 0;
-      } else {
-        alive = true;
-      }
-
+      alive = shade_vertex<IN_LDS, ALL_OPAQUE>(sc, f, st, tr, n_lights, bg_linear, slot, hit, ray_dir, p, next_o, next_d, tally, walks);
       if (alive) {
         st.ray_o[slot] = make_float4(next_o.x, next_o.y, next_o.z, 0.0f);
         st.ray_d[slot] = make_float4(next_d.x, next_d.y, next_d.z, 0.0f);
       }
-      st.path_a[slot] = make_float4(indirect.x, indirect.y, indirect.z, ubits(rng));
-      st.path_b[slot] = make_float4(color.x, color.y, color.z, ubits(ctr_pack(light_steps, transp_steps, false, sample)));
+      st.path_a[slot] = make_float4(p.indirect.x, p.indirect.y, p.indirect.z, ubits(p.rng));
+      st.path_b[slot] = make_float4(p.color.x, p.color.y, p.color.z, ubits(ctr_pack(p.light_steps, p.transp_steps, false, p.sample)));
     }
 
     // queue compaction (the whole block converges here)
     const AppendSlots at = block_append2(alive, &st.counters[PT_CNT_QUEUE0 + (parity ^ 1u)], false, nullptr);
     if (alive) st.queue[parity ^ 1u][at.a] = slot;
   }
+  flush_tally(tally, st, PT_K_SHADE);
+  flush_tally(walks, st, PT_K_SHADOW);
+}
+
+// The tail of a frame. A pixel's samples are sequential (one RNG stream per pixel, Q2), so
+// the last few hundred iterations carry only the slots whose every path runs all 8 bounces:
+// too few rays to fill the GPU, and every iteration still pays two launches' worth of
+// dependent global round trips (~45 us measured on cfg2 for < 100 k rays). Once the queue is
+// that short the remaining work of every queued slot — extend, shade, extend, ... until its
+// last sample ends — runs inside ONE launch, one lane per slot. Same functions, same order
+// per slot, so the results are unchanged.
+template <bool IN_LDS, bool ALL_OPAQUE>
+__global__ __launch_bounds__(256, PT_SHADE_MIN_WAVES) void k_tail(pt_dev_scene sc, pt_dev_frame f, pt_dev_state st, uint32_t parity,
+                                                                  uint32_t max_vertices) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
+  const uint32_t n = st.counters[PT_CNT_QUEUE0 + parity];
+  Tally ext, tally, walks;
+  const uint32_t n_lights = sc.directional_light_count + sc.point_light_count + (f.pc.emissive_triangle_count ? 1u : 0u);
+  const vec3 bg_linear = mk(f.bg_linear[0], f.bg_linear[1], f.bg_linear[2]);
+  if (blockIdx.x * blockDim.x < n) {  // block-uniform
+    const Tracer tr = make_tracer<IN_LDS>(sc, lds_dyn);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+      const uint32_t slot = st.queue[parity][i];
+      const float4 o4 = st.ray_o[slot], d4 = st.ray_d[slot];
+      const float4 pa = st.path_a[slot], pb = st.path_b[slot];
+      const uint32_t ctr = fbits(pb.w);
+      PathRegs p{xyz(pa), xyz(pb), fbits(pa.w), ctr_light(ctr), ctr_transp(ctr), ctr_sample(ctr)};
+      bool primary = ctr_primary(ctr);
+      vec3 o = xyz(o4), d = xyz(d4);
+      for (uint32_t k = 0; k < max_vertices; ++k) {  // bounded: every wave reaches the end of the grid
+        Hit h{kInfinity, 0.0f, 0.0f, kNoHit};
+        traverse<IN_LDS, false>(tr, o, d, h, ext);
+        if (primary) st.primary_id[slot] = h.tri;
+        primary = false;
+        vec3 next_o = mk(0, 0, 0), next_d = mk(0, 0, 0);
+        if (!shade_vertex<IN_LDS, ALL_OPAQUE>(sc, f, st, tr, n_lights, bg_linear, slot, h, d, p, next_o, next_d, tally, walks)) break;
+        o = next_o;
+        d = next_d;
+      }
+      st.path_a[slot] = make_float4(p.indirect.x, p.indirect.y, p.indirect.z, ubits(p.rng));
+      st.path_b[slot] = make_float4(p.color.x, p.color.y, p.color.z, ubits(ctr_pack(p.light_steps, p.transp_steps, false, p.sample)));
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) st.counters[PT_CNT_QUEUE0 + parity] = 0;  // drained (n was read above by this thread)
+  flush_tally(ext, st, PT_K_EXTEND);
   flush_tally(tally, st, PT_K_SHADE);
   flush_tally(walks, st, PT_K_SHADOW);
 }
@@ -923,8 +1043,26 @@ void launch_shade(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_st
   uint32_t grid = blocks_for(max_entries, block);
   if (grid > max_blocks) grid = max_blocks;
   const size_t lds = has_lights ? trace_lds_bytes(sc, block) : 0;
-  if (sc.scene_in_lds) hipLaunchKernelGGL(k_shade<true>, dim3(grid), dim3(block), lds, s, sc, f, st, parity);
-  else hipLaunchKernelGGL(k_shade<false>, dim3(grid), dim3(block), lds, s, sc, f, st, parity);
+  const int variant = (sc.scene_in_lds ? 2 : 0) | (sc.all_opaque ? 1 : 0);
+  switch (variant) {
+    case 3: hipLaunchKernelGGL((k_shade<true, true>), dim3(grid), dim3(block), lds, s, sc, f, st, parity); break;
+    case 2: hipLaunchKernelGGL((k_shade<true, false>), dim3(grid), dim3(block), lds, s, sc, f, st, parity); break;
+    case 1: hipLaunchKernelGGL((k_shade<false, true>), dim3(grid), dim3(block), lds, s, sc, f, st, parity); break;
+    default: hipLaunchKernelGGL((k_shade<false, false>), dim3(grid), dim3(block), lds, s, sc, f, st, parity); break;
+  }
+}
+
+void launch_tail(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity, uint32_t max_entries,
+                 uint32_t block, uint32_t max_vertices, hipStream_t s) {
+  const uint32_t grid = blocks_for(max_entries, block);
+  const size_t lds = trace_lds_bytes(sc, block);
+  const int variant = (sc.scene_in_lds ? 2 : 0) | (sc.all_opaque ? 1 : 0);
+  switch (variant) {
+    case 3: hipLaunchKernelGGL((k_tail<true, true>), dim3(grid), dim3(block), lds, s, sc, f, st, parity, max_vertices); break;
+    case 2: hipLaunchKernelGGL((k_tail<true, false>), dim3(grid), dim3(block), lds, s, sc, f, st, parity, max_vertices); break;
+    case 1: hipLaunchKernelGGL((k_tail<false, true>), dim3(grid), dim3(block), lds, s, sc, f, st, parity, max_vertices); break;
+    default: hipLaunchKernelGGL((k_tail<false, false>), dim3(grid), dim3(block), lds, s, sc, f, st, parity, max_vertices); break;
+  }
 }
 
 void launch_finalize(const pt_dev_frame& f, const pt_dev_state& st, float4* accum_out, uint32_t* primary_out, hipStream_t s) {

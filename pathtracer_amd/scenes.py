@@ -265,3 +265,218 @@ def soup_scene(n_tris: int, seed: int = 20261111, extent: float = 10.0, edge: fl
     s.camera_lookat = (0.0, 0.0, -1.0)
     s.camera_vfov = float(np.float32(math.radians(45.0)))
     return s
+
+
+# ------------------------------------------------------------------ parametric surfaces
+def _surface(f, nu: int, nv: int, mat: int, uv_scale=(1.0, 1.0), flip: bool = False):
+    """Tessellate pos = f(u, v), (u, v) in [0,1]^2, into 2*nu*nv triangles with smooth
+    normals (cross product of central differences) and uv = (u, v) * uv_scale."""
+    u = np.linspace(0.0, 1.0, nu + 1)
+    v = np.linspace(0.0, 1.0, nv + 1)
+    U, V = np.meshgrid(u, v, indexing="ij")
+    P = f(U, V)
+    h = 1e-4
+    du = (f(np.clip(U + h, 0, 1), V) - f(np.clip(U - h, 0, 1), V))
+    dv = (f(U, np.clip(V + h, 0, 1)) - f(U, np.clip(V - h, 0, 1)))
+    N = np.cross(du, dv)
+    if flip:
+        N = -N
+    ln = np.linalg.norm(N, axis=-1, keepdims=True)
+    N = np.where(ln > 1e-20, N / np.maximum(ln, 1e-20), np.array([0.0, 1.0, 0.0]))
+    idx = np.arange((nu + 1) * (nv + 1)).reshape(nu + 1, nv + 1)
+    a, b, c, d = idx[:-1, :-1], idx[1:, :-1], idx[1:, 1:], idx[:-1, 1:]
+    if flip:
+        tris = np.stack([np.stack([a, c, b], -1), np.stack([a, d, c], -1)], axis=2)
+    else:
+        tris = np.stack([np.stack([a, b, c], -1), np.stack([a, c, d], -1)], axis=2)
+    uv = np.stack([U * uv_scale[0], V * uv_scale[1]], -1)
+    n = (nu + 1) * (nv + 1)
+    return (P.reshape(n, 3), N.reshape(n, 3), uv.reshape(n, 2), np.full(n, mat, dtype=np.int32), tris.reshape(-1, 3))
+
+
+class _BigMesh:
+    """Array-based mesh accumulator for the large generated scenes."""
+
+    def __init__(self):
+        self.parts = []
+        self.count = 0
+
+    def add(self, pos, nrm, uv, mat, tris):
+        self.parts.append((np.asarray(pos, np.float32), np.asarray(nrm, np.float32), np.asarray(uv, np.float32),
+                           np.asarray(mat, np.int32), np.asarray(tris, np.uint32) + np.uint32(self.count)))
+        self.count += len(pos)
+
+    def scene(self, **kw) -> Scene:
+        pos, nrm, uv, mat, tris = (np.concatenate([p[k] for p in self.parts]) for k in range(5))
+        # drop zero-area triangles (sphere poles): the shader could never hit them (Q11)
+        P = pos[tris.reshape(-1)].reshape(-1, 3, 3).astype(np.float64)
+        area2 = np.linalg.norm(np.cross(P[:, 1] - P[:, 0], P[:, 2] - P[:, 0]), axis=1)
+        tris = tris[area2 > 1e-9]
+        return Scene(vertices=_verts(pos, nrm, uv, mat), triangles=tris, **kw)
+
+
+def atrium_scene(detail: int = 16, tex_size: int = 1024, n_materials: int = 24, seed: int = 3) -> Scene:
+    """cfg3: a generated "Sponza-class" textured PBR atrium: a long hall with a
+    relief floor, two storeys of colonnades with arches, relief walls, a vaulted ceiling open to
+    the sky along its ridge, cloth banners with alpha cut-outs, emissive lamps, one directional
+    (sun) light. detail=16 gives ~262 k triangles; every material has a tex_size^2 PNG-able
+    base-colour map and a metal-rough map (linear / repeat)."""
+    rng = np.random.RandomState(seed)
+    d = max(1, int(detail))
+    m = _BigMesh()
+    L, W, H = 24.0, 8.0, 9.0  # hall length (x), half-width (z), height (y)
+
+    n_tex_mats = max(4, n_materials - 2)
+    MAT = lambda k: 1 + (k % n_tex_mats)  # textured PBR materials 1..n_tex_mats
+    LAMP = n_tex_mats + 1
+    CLOTH = n_tex_mats + 2
+
+    def bump(U, V, fu, fv, amp):
+        return amp * (np.sin(U * fu * 2 * math.pi) * np.sin(V * fv * 2 * math.pi))
+
+    # floor and upper gallery floors (relief tiles)
+    m.add(*_surface(lambda U, V: np.stack([-L + 2 * L * U, bump(U, V, 24, 8, 0.015), -W + 2 * W * V], -1),
+                    10 * d, 4 * d, MAT(0), (12, 4), flip=True))
+    for side in (-1, 1):
+        z0, z1 = (side * W, side * (W - 2.5)) if side < 0 else (side * (W - 2.5), side * W)
+        m.add(*_surface(lambda U, V, z0=z0, z1=z1: np.stack([-L + 2 * L * U, 4.2 + bump(U, V, 30, 3, 0.01), z0 + (z1 - z0) * V], -1),
+                        8 * d, d, MAT(1), (16, 2), flip=True))
+        m.add(*_surface(lambda U, V, z0=z0, z1=z1: np.stack([-L + 2 * L * U, 4.0 + 0 * U, z0 + (z1 - z0) * V], -1),
+                        4 * d, max(1, d // 2), MAT(2), (16, 2)))
+    # side walls and end walls with brick relief
+    for side in (-1, 1):
+        m.add(*_surface(lambda U, V, s=side: np.stack([-L + 2 * L * U, H * V, s * (W + bump(U, V, 40, 18, 0.02))], -1),
+                        10 * d, 4 * d, MAT(3 + (side > 0)), (10, 4), flip=(side > 0)))
+        m.add(*_surface(lambda U, V, s=side: np.stack([s * (L + bump(U, V, 14, 18, 0.02)), H * V, -W + 2 * W * U], -1),
+                        4 * d, 4 * d, MAT(5 + (side > 0)), (4, 4), flip=(side < 0)))
+    # vaulted ceiling, open slot along the ridge (sky light enters)
+    for side in (-1, 1):
+        m.add(*_surface(lambda U, V, s=side: np.stack([-L + 2 * L * U,
+                                                        H + 2.0 * np.sin(V * 0.45 * math.pi),
+                                                        s * W * (1.0 - 0.62 * V) + 0 * U], -1),
+                        8 * d, 2 * d, MAT(7), (12, 2), flip=(side < 0)))
+    # colonnades: two storeys, both sides; columns + arches
+    n_col = 10
+    xs = np.linspace(-L + 2.4, L - 2.4, n_col)
+    for storey, (y0, y1, r) in enumerate([(0.0, 3.2, 0.32), (4.2, 7.0, 0.24)]):
+        for side in (-1, 1):
+            zc = side * (W - 2.5)
+            for ci, xc in enumerate(xs):
+                mat = MAT(8 + storey * 2 + (ci % 2))
+                flute = 12
+                m.add(*_surface(lambda U, V, xc=xc, zc=zc, y0=y0, y1=y1, r=r: np.stack([
+                    xc + (r * (1 + 0.06 * np.cos(U * flute * 2 * math.pi)) * (1 + 0.25 * (np.exp(-V * 14) + np.exp(-(1 - V) * 14)))) * np.cos(U * 2 * math.pi),
+                    y0 + (y1 - y0) * V,
+                    zc + (r * (1 + 0.06 * np.cos(U * flute * 2 * math.pi)) * (1 + 0.25 * (np.exp(-V * 14) + np.exp(-(1 - V) * 14)))) * np.sin(U * 2 * math.pi)], -1),
+                    3 * d, 2 * d, mat, (3, 4), flip=True))
+                if ci + 1 < n_col:  # arch to the next column: a half-ring band
+                    xn = xs[ci + 1]
+                    span = (xn - xc) / 2
+                    m.add(*_surface(lambda U, V, xm=(xc + xn) / 2, span=span, zc=zc, y1=y1, r=r: np.stack([
+                        xm - (span - r * (0.2 + 0.6 * V) * 0) * np.cos(U * math.pi) * (1 - 0.08 * V),
+                        y1 + 0.8 * span * np.sin(U * math.pi) * (1 - 0.08 * V) * 0.55,
+                        zc + (V - 0.5) * 2 * r + 0 * U], -1),
+                        2 * d, max(1, d // 2), MAT(12 + storey), (4, 1)))
+    # cloth banners with alpha cut-outs hanging from the upper gallery
+    for k, xc in enumerate(np.linspace(-L + 5, L - 5, 6)):
+        side = -1 if k % 2 else 1
+        m.add(*_surface(lambda U, V, xc=xc, s=side, ph=k: np.stack([
+            xc + 1.6 * (U - 0.5), 7.6 - 3.0 * V, s * (W - 2.9) + 0.12 * np.sin(U * 3 * math.pi + ph) * (0.3 + V)], -1),
+            d, 2 * d, CLOTH, (1, 2)))
+    # emissive lamps: glowing globes under the gallery (NEE towards an opaque emitter returns 0
+    # in the reference's estimator, Q5: their light arrives through BSDF-sampled hits only)
+    for k, xc in enumerate(np.linspace(-L + 3.6, L - 3.6, 8)):
+        for side in (-1, 1):
+            m.add(*_surface(lambda U, V, xc=xc, s=side: np.stack([
+                xc + 0.45 * np.sin(V * math.pi) * np.cos(U * 2 * math.pi),
+                3.3 + 0.45 * np.cos(V * math.pi),
+                s * (W - 1.25) + 0.45 * np.sin(V * math.pi) * np.sin(U * 2 * math.pi)], -1),
+                max(4, d // 2), max(3, d // 3), LAMP, (1, 1)))
+
+    # materials + textures: image i+1 / texture 2k, 2k+1 per textured material k
+    imgs = [default_image()]
+    textures = []
+    mats = [default_material()]
+    samplers = np.zeros(2, dtype=abi.SAMPLER)
+    samplers[0] = default_sampler()[0]
+    samplers[1] = (abi.FILTER_LINEAR, abi.FILTER_LINEAR, abi.WRAP_REPEAT, abi.WRAP_REPEAT)
+    for k in range(n_tex_mats):
+        imgs.append(procedural_texture(tex_size, seed * 100 + 2 * k, "color"))
+        imgs.append(procedural_texture(tex_size, seed * 100 + 2 * k + 1, "mr"))
+        textures += [(1, len(imgs) - 2), (1, len(imgs) - 1)]
+        mats.append(make_material((1, 1, 1, 1), 1.0, 1.0, base_color_texture=2 * k, metallic_roughness_texture=2 * k + 1))
+    mats.append(make_material((0, 0, 0, 1), emissive=(30.0, 24.0, 14.0)))  # LAMP
+    imgs.append(procedural_texture(min(tex_size, 256), seed * 100 + 99, "alpha"))
+    textures.append((1, len(imgs) - 1))
+    mats.append(make_material((0.9, 0.9, 0.9, 1.0), 0.0, 0.8, base_color_texture=len(textures) - 1))  # CLOTH
+    tex = np.zeros(len(textures), dtype=abi.TEXTURE)
+    for i, (s_, im_) in enumerate(textures):
+        tex[i] = (s_, im_)
+    dl = np.zeros(2, dtype=abi.DIRECTIONAL_LIGHT)
+    sun = np.array([0.25, -1.0, 0.35])
+    sun /= np.linalg.norm(sun)
+    dl[0]["color"], dl[0]["intensity"], dl[0]["direction"] = (1.0, 0.96, 0.88), 6.0, sun
+    s = m.scene(materials=np.concatenate(mats), images=imgs, samplers=samplers, textures=tex, directional_lights=dl)
+    s.camera_position = (-L + 1.5, 2.2, 0.6)
+    look = np.array([1.0, 0.12, -0.04])
+    look /= np.linalg.norm(look)
+    s.camera_lookat = tuple(float(np.float32(x)) for x in look)
+    s.camera_vfov = float(np.float32(math.radians(55.0)))
+    return s
+
+
+def rocks_scene(n_tris: int = 5_000_000, seed: int = 20261111, extent: float = 50.0, res: int = 16) -> Scene:
+    """cfg4: procedural ~n_tris-triangle scene: seeded clusters of displaced
+    spheres ("rocks", 2*res*2res triangles each, radius 0.4..2.5, edge lengths ~0.05..0.5 so
+    areas stay far above the 1e-6 cut-off, Q11) scattered through a (2*extent)^3 volume over
+    a tessellated ground, diffuse + metal material mix, sky background, one directional light."""
+    rng = np.random.RandomState(seed)
+    nu, nv = 2 * res, res
+    per_rock = 2 * nu * nv
+    ground_n = max(8, int(math.sqrt(n_tris * 0.04 / 2)))
+    n_rocks = max(1, (n_tris - 2 * ground_n * ground_n) // per_rock)
+    m = _BigMesh()
+    n_mats = 8
+    # ground
+    m.add(*_surface(lambda U, V: np.stack([-extent + 2 * extent * U,
+                                           -extent + 0.6 * np.sin(U * 37.0) * np.cos(V * 29.0),
+                                           -extent + 2 * extent * V], -1), ground_n, ground_n, 1, (40, 40), flip=True))
+    # rocks in clusters
+    n_clusters = max(1, n_rocks // 6)
+    centers = rng.uniform(-extent * 0.9, extent * 0.9, size=(n_clusters, 3))
+    centers[:, 1] = rng.uniform(-extent * 0.95, extent * 0.4, size=n_clusters)
+    u = np.linspace(0.0, 1.0, nu + 1)
+    v = np.linspace(0.0, 1.0, nv + 1)
+    U, V = np.meshgrid(u, v, indexing="ij")
+    theta, phi = U * 2 * math.pi, V * math.pi
+    sph = np.stack([np.sin(phi) * np.cos(theta), np.cos(phi), np.sin(phi) * np.sin(theta)], -1)  # unit sphere grid
+    idx = np.arange((nu + 1) * (nv + 1)).reshape(nu + 1, nv + 1)
+    a, b, c, d_ = idx[:-1, :-1], idx[1:, :-1], idx[1:, 1:], idx[:-1, 1:]
+    tris = np.stack([np.stack([a, c, b], -1), np.stack([a, d_, c], -1)], axis=2).reshape(-1, 3)
+    uv = np.stack([U * 2, V], -1).reshape(-1, 2)
+    nvert = (nu + 1) * (nv + 1)
+    for k in range(n_rocks):
+        ctr = centers[k % n_clusters] + rng.normal(0.0, 2.5, size=3)
+        radius = rng.uniform(0.4, 2.5)
+        f1, f2, f3 = rng.randint(2, 6, size=3)
+        p1, p2 = rng.uniform(0, 6.28, size=2)
+        disp = 1.0 + 0.18 * np.sin(f1 * theta + p1) * np.sin(f2 * phi) + 0.08 * np.cos(f3 * theta + p2) * np.sin(3 * phi)
+        P = ctr + radius * disp[..., None] * sph
+        N = sph * np.array(rng.uniform(0.9, 1.1, size=3))  # smooth-ish shading normals
+        N /= np.linalg.norm(N, axis=-1, keepdims=True)
+        m.add(P.reshape(nvert, 3), N.reshape(nvert, 3), uv, np.full(nvert, 1 + (k % n_mats), np.int32), tris)
+    mats = [default_material()]
+    for k in range(n_mats):
+        col = tuple(0.25 + 0.7 * rng.rand(3)) + (1.0,)
+        mats.append(make_material(col, metallic=float(k % 3 == 0), roughness=0.15 + 0.1 * k))
+    dl = np.zeros(2, dtype=abi.DIRECTIONAL_LIGHT)
+    sun = np.array([0.3, -1.0, 0.25])
+    sun /= np.linalg.norm(sun)
+    dl[0]["color"], dl[0]["intensity"], dl[0]["direction"] = (1.0, 0.98, 0.92), 3.0, sun
+    s = m.scene(materials=np.concatenate(mats), directional_lights=dl)
+    s.camera_position = (0.0, -extent * 0.3, extent * 1.25)
+    look = np.array([0.0, -0.05, -1.0])
+    look /= np.linalg.norm(look)
+    s.camera_lookat = tuple(float(np.float32(x)) for x in look)
+    s.camera_vfov = float(np.float32(math.radians(45.0)))
+    return s

@@ -11,7 +11,8 @@ for f in sorted(glob.glob(os.path.join(out, "pass*", "**", "*counter_collection.
             calls[k].add((f, row["Dispatch_Id"]))
 lines = []
 for k in sorted(tot):
-    lines.append(f"{k}")
+    n_disp = max(len({d for f2, d in calls[k] if f2 == f0}) for f0 in {f for f, _ in calls[k]})
+    lines.append(f"{k}  dispatches={n_disp}")
     for c in sorted(tot[k]):
         lines.append(f"  {c:40s} {tot[k][c]:.6g}")
 txt = "\n".join(lines)

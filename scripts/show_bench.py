@@ -1,0 +1,15 @@
+#!/usr/bin/env python3
+"""Print the headline numbers of bench.py JSON lines: scripts/show_bench.py gpurun_out/a.json ..."""
+import json
+import sys
+for f in sys.argv[1:]:
+    try:
+        d = json.load(open(f))
+    except Exception as e:
+        print(f, "unreadable:", e)
+        continue
+    print(f"{f}: {d['value']:.0f} Mrays/s  {d['mpaths_per_s']:.0f} Mpaths/s  {d['ms_per_step']:.1f} ms/step  iters {d['config']['iterations']}")
+    for k, v in d.get("kernels", {}).items():
+        print(f"   {k:7s} launches {v['launches']:5d}  avg {v['avg_launch_us']:8.1f} us  {v['hbm']['achieved']:7.0f} GB/s (frac {v['hbm']['frac']:.3f})  valu {v['valu']['achieved']:.2f} TF")
+    if "cpu_baseline" in d:
+        print("   cpu:", d["cpu_baseline"]["value"], d["cpu_baseline"]["unit"], d["cpu_baseline"]["cores"], "threads")

@@ -81,6 +81,15 @@ def test_soup_deep_bvh(renderer, oracle):
     compare(renderer, oracle, scenes.soup_scene(20000, emissive_every=50), 160, 90, 9, seed=14)
 
 
+def test_atrium_cfg3_class_textured(renderer, oracle):
+    # the cfg3 generator at low tessellation: relief walls, columns, arches, alpha cloth, emissive globes, sun
+    compare(renderer, oracle, scenes.atrium_scene(detail=2, tex_size=64), 160, 90, 9, seed=21, bg=(0.5, 0.7, 1.0))
+
+
+def test_rocks_cfg4_class_deep_bvh(renderer, oracle):
+    compare(renderer, oracle, scenes.rocks_scene(60000), 160, 90, 9, seed=22, bg=(0.5, 0.7, 1.0))
+
+
 def test_ragged_resolution_and_single_sample(renderer, oracle):
     # not a multiple of the 8x8 slot tile, portrait, 1 spp
     compare(renderer, oracle, scenes.cornell_scene(with_point_light=True), 37, 53, 1, seed=15)
