@@ -55,6 +55,7 @@ struct pt_ctx {
   uint32_t band_slots = 0;          // 0 = whole frame in one band
   uint32_t trace_blocks = 0;        // grid cap of k_extend (persistent workgroups striding the queue)
   uint32_t shade_blocks = 0;        // grid cap of k_shade
+  bool split_shadow = true;         // scenes in global memory: shadow walks in their own kernel (PT_SPLIT_SHADOW=0 keeps them in k_shade)
   uint32_t tail_entries = 262144;   // queue length below which the rest of the frame runs in one k_tail launch (0 = never)
   uint32_t lds_scene_bytes = 12288; // scenes up to this size (pair records + triangle positions) are staged whole in LDS
   uint32_t* host_counts = nullptr;  // pinned
@@ -191,6 +192,11 @@ int ensure_state(pt_ctx* ctx, uint32_t slots, uint32_t lights, uint32_t pixels) 
   ALLOC(st.primary_id, slots);
   ALLOC(st.queue[0], slots);
   ALLOC(st.queue[1], slots);
+  st.slot_stride = slots;
+  // split pipeline buffers (only used when the scene is read from global memory and has lights)
+  ALLOC(st.pend, lights ? 5 * static_cast<size_t>(slots) : 0);
+  ALLOC(st.req, 4 * static_cast<size_t>(lights) * slots);
+  ALLOC(st.queue_shadow, lights ? slots : 0);
   ALLOC(st.counters, PT_CNT_WORDS);
   st.stat_rows = slots / 64 + 1;
   ALLOC(st.stats, static_cast<size_t>(PT_K_COUNT) * st.stat_rows * PT_ST_WORDS);
@@ -251,6 +257,7 @@ extern "C" pt_ctx* pt_create(int device) {
   if (const char* e = std::getenv("PT_LDS_SCENE_BYTES")) ctx->lds_scene_bytes = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   if (ctx->trace_blocks == 0) ctx->trace_blocks = 2048;
   if (ctx->lds_scene_bytes > 32768) ctx->lds_scene_bytes = 32768;
+  if (const char* e = std::getenv("PT_SPLIT_SHADOW")) ctx->split_shadow = std::strtoul(e, nullptr, 10) != 0;
   if (const char* e = std::getenv("PT_TAIL_ENTRIES")) ctx->tail_entries = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   if (const char* e = std::getenv("PT_BAND_SLOTS")) ctx->band_slots = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   bool ok = hipSetDevice(device) == hipSuccess &&
@@ -477,16 +484,16 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
   uint32_t band_slots = ctx->band_slots ? ctx->band_slots : total_slots;
   band_slots = (band_slots + 63u) & ~63u;
   if (band_slots > total_slots) band_slots = total_slots;
-  int rc = ensure_state(ctx, band_slots, n_lights, pixels);
-  if (rc != PT_OK) return rc;
-  const pt_dev_state& st = ctx->state;
-  if (!accum_dev) accum_dev = ctx->accum_out;
-  if (!primary_dev) primary_dev = ctx->primary_out;
-
   // traversal block size: stack (block * stack_entries words) + the scene copy, kept within 64 KiB
   const uint32_t scene_lds = sc.scene_in_lds ? 64u * sc.pair_count + 48u * sc.triangle_count : 0u;
   if (256u * sc.stack_entries * 4u + scene_lds > 65536u) sc.scene_in_lds = 0;  // deep tree: the stack needs the LDS
   const uint32_t trace_block = (256u * sc.stack_entries * 4u <= 65536u) ? 256u : 64u;
+  const bool split = ctx->split_shadow && !sc.scene_in_lds && n_lights != 0;
+  int rc = ensure_state(ctx, band_slots, split ? n_lights : 0u, pixels);
+  if (rc != PT_OK) return rc;
+  const pt_dev_state& st = ctx->state;
+  if (!accum_dev) accum_dev = ctx->accum_out;
+  if (!primary_dev) primary_dev = ctx->primary_out;
   const bool time_kernels = (p->flags & PT_FLAG_TIME_KERNELS) != 0;
   size_t ev_used = 0;
   std::vector<std::pair<size_t, int>> ev_kind;  // index of the start event, kernel id
@@ -530,7 +537,8 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
       for (uint32_t b = 0; b < kBatch; ++b, ++iter) {
         const uint32_t parity = static_cast<uint32_t>(iter & 1u);
         timed(PT_K_EXTEND, [&] { ptd::launch_extend(sc, st, parity, bound, trace_block, ctx->trace_blocks, stream); });
-        timed(PT_K_SHADE, [&] { ptd::launch_shade(sc, f, st, parity, bound, trace_block, ctx->shade_blocks, n_lights != 0, stream); });
+        timed(PT_K_SHADE, [&] { ptd::launch_shade(sc, f, st, parity, bound, trace_block, ctx->shade_blocks, n_lights != 0, split, stream); });
+        if (split) timed(PT_K_SHADOW, [&] { ptd::launch_shadow(sc, f, st, bound, trace_block, ctx->trace_blocks, stream); });
       }
       PT_HIP(ctx, hipGetLastError());
       // entries queued for the NEXT iteration; stays intact until that iteration's successor recycles it

@@ -8,7 +8,7 @@
 #include "pathtracer_amd.h"
 
 // counters[] words
-enum { PT_CNT_QUEUE0 = 0, PT_CNT_QUEUE1 = 1, PT_CNT_WORDS = 4 };
+enum { PT_CNT_QUEUE0 = 0, PT_CNT_QUEUE1 = 1, PT_CNT_SHADOW = 2, PT_CNT_WORDS = 4 };
 // stats[] words (unsigned long long), order of flush_tally()
 enum { PT_ST_PATHS = 0, PT_ST_RAYS, PT_ST_VISITS, PT_ST_TESTS, PT_ST_HITS, PT_ST_TAPS, PT_ST_VERTS, PT_ST_NANS, PT_ST_WORDS };
 // one block of PT_ST_WORDS per kernel
@@ -67,6 +67,11 @@ struct pt_dev_state {
   float4* accum;       // sum of valid samples .xyz, dropped-sample count
   uint32_t* primary_id;
   uint32_t* queue[2];
+  // split pipeline (scenes in global memory with lights): per-slot deferred direct-light update
+  float4* pend;           // [5][slot_stride]: emission|alpha factor, throughput|flags, shadow origin, colour, end throughput
+  float4* req;            // [n_lights][4][slot_stride]: l|limit, factor|correction, brdf|n.l, pdf|emitter|tap
+  uint32_t* queue_shadow; // slots whose vertex k_shadow has to finish
+  uint32_t slot_stride;
   uint32_t* counters;
   unsigned long long* stats;  // [kernel][stat_rows][PT_ST_WORDS]: one row per block index, no atomics
   uint32_t stat_rows;         // >= the largest grid (slot_count / 64 + 1)
@@ -77,7 +82,9 @@ void launch_init(const pt_dev_frame& f, const pt_dev_state& st, hipStream_t s);
 void launch_extend(const pt_dev_scene& sc, const pt_dev_state& st, uint32_t parity, uint32_t max_entries, uint32_t block,
                    uint32_t max_blocks, hipStream_t s);
 void launch_shade(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity,
-                  uint32_t max_entries, uint32_t block, uint32_t max_blocks, bool has_lights, hipStream_t s);
+                  uint32_t max_entries, uint32_t block, uint32_t max_blocks, bool has_lights, bool split, hipStream_t s);
+void launch_shadow(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t max_entries, uint32_t block,
+                   uint32_t max_blocks, hipStream_t s);
 void launch_tail(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity, uint32_t max_entries,
                  uint32_t block, uint32_t max_vertices, hipStream_t s);
 void launch_finalize(const pt_dev_frame& f, const pt_dev_state& st, float4* accum_out, uint32_t* primary_out, hipStream_t s);

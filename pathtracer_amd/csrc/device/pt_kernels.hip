@@ -311,9 +311,42 @@ __device__ __forceinline__ void traverse(const Tracer& tr, vec3 o, vec3 d, Hit& 
         if (leaf()) return;
     }
   } else {
-    while (live) {
-      if (cnt == 0) inner();
-      else if (leaf()) return;
+    for (;;) {
+      if (cnt > 0) {
+        if (ANY_HIT) {
+          for (uint32_t i = 0; i < cnt; ++i) {
+            ++tally.tests;
+            ray_triangle<IN_LDS>(tr, o, d, ref + i, h);
+            if (h.tri != kNoHit) return;
+          }
+        } else {
+          tally.tests += cnt;
+          for (uint32_t i = 0; i < cnt; ++i) ray_triangle<IN_LDS>(tr, o, d, ref + i, h);
+        }
+      } else {
+        ++tally.visits;
+        const float4 l0 = fetch16<IN_LDS>(tr.pairs, 4 * ref), l1 = fetch16<IN_LDS>(tr.pairs, 4 * ref + 1);
+        const float4 r0 = fetch16<IN_LDS>(tr.pairs, 4 * ref + 2), r1 = fetch16<IN_LDS>(tr.pairs, 4 * ref + 3);
+        float dist_l, dist_r;
+        bool hit_l, hit_r;
+        ray_box_pair(o, inv, l0, l1, r0, r1, h.t, hit_l, hit_r, dist_l, dist_r);
+        if (hit_l || hit_r) {
+          const bool go_left = hit_l && (!hit_r || dist_l < dist_r);
+          if (hit_l && hit_r) {
+            tr.stack[sp * tr.stride] = (ref << 1) | (go_left ? 1u : 0u);
+            ++sp;
+          }
+          ref = go_left ? fbits(l0.w) : fbits(r0.w);
+          cnt = go_left ? fbits(l1.w) : fbits(r1.w);
+          continue;
+        }
+      }
+      if (sp == 0) break;
+      --sp;
+      const uint32_t e = tr.stack[sp * tr.stride];
+      const uint32_t word = 4u * (e >> 1) + 2u * (e & 1u);
+      ref = fbits(fetch16<IN_LDS>(tr.pairs, word).w);
+      cnt = fbits(fetch16<IN_LDS>(tr.pairs, word + 1u).w);
     }
   }
 }
@@ -625,6 +658,7 @@ __global__ __launch_bounds__(256) void k_extend(pt_dev_scene sc, pt_dev_state st
   const uint32_t n = st.counters[PT_CNT_QUEUE0 + parity];
   if (blockIdx.x == 0 && threadIdx.x == 0) {  // recycle the counters the previous iteration consumed
     st.counters[PT_CNT_QUEUE0 + (parity ^ 1u)] = 0;
+    st.counters[PT_CNT_SHADOW] = 0;
   }
   Tally tally;
   if (blockIdx.x * blockDim.x < n) {  // block-uniform
@@ -689,14 +723,25 @@ struct PathRegs {
   uint32_t rng, light_steps, transp_steps, sample;
 };
 
-template <bool IN_LDS, bool ALL_OPAQUE>
+// SPLIT (scenes read from global memory with at least one light): the shadow walks do NOT run
+// here. Every light sample is written as a request (direction, the factors of its
+// contribution, the distance test's operands) and the vertex's `color +=` is deferred to
+// k_shadow, which walks at k_extend's occupancy instead of this kernel's (measured: the walks
+// ran 2x slower per ray inside the 128..168-register shading kernel). `shaded` tells the
+// caller to queue the slot for k_shadow. The deferred arithmetic is the same expressions in
+// the same order, so results stay bit-identical to the fused form.
+template <bool IN_LDS, bool ALL_OPAQUE, bool SPLIT>
 __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st,
                                              const Tracer& tr, uint32_t n_lights, vec3 bg_linear, uint32_t slot,
                                              const Hit& hit, vec3 ray_dir, PathRegs& p, vec3& next_o, vec3& next_d,
-                                             Tally& tally, Tally& walks) {
+                                             Tally& tally, Tally& walks, bool& shaded) {
   vec3 indirect = p.indirect, color = p.color;
   uint32_t rng = p.rng, light_steps = p.light_steps, transp_steps = p.transp_steps, sample = p.sample;
   bool alive = false;
+  shaded = false;
+  float alpha_factor = 1.0f;   // SPLIT: what `direct` is multiplied by before `* indirect` (main.comp:545 / :552)
+  vec3 deferred_m = splat(0.0f), deferred_emission = splat(0.0f), deferred_origin = splat(0.0f);
+  const vec3 color_in = color;
   bool path_done = false;  // the sample ends at this vertex
 
   if (hit.tri == kNoHit) {  // main.comp:517 -> :580
@@ -779,6 +824,46 @@ __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const pt_de
         l = normalize(l);
       }
 
+      if (SPLIT) {
+        vec3 a_factor;       // the radiance / emission factor that transparency multiplies
+        float n_dot_l, pdf = 1.0f, limit = -kInfinity * 2.0f, correction = 0.0f;  // -inf: `x < limit` never holds (no distance test for directional lights)
+        uint32_t tap_if_visible = 0;
+        if (kind == 0u) {
+          n_dot_l = gmax(dot(nrm, l), 0.0f);
+          a_factor = xyz(l0) * l0.w;
+        } else {
+          correction = kNormalDelta / dot(l, nrm);
+          limit = length(pos - sample_pos);
+          n_dot_l = __builtin_fabsf(dot(nrm, l));
+          if (kind == 1u) {
+            a_factor = xyz(l0) * l0.w / kLightArea / kFourPi;
+            const float cos_theta0 = dot(sample_dir, -l);
+            pdf = dist2 / (cos_theta0 * kLightArea);
+          } else {
+            const TriAttr at = load_attr(sc.tri_attr, etri);
+            vec3 tri_n = normalize(mat3_mul(at.n0, at.n1, at.n2, ewuv));
+            const float eu = at.u0 * ewuv.x + at.u1 * ewuv.y + at.u2 * ewuv.z;
+            const float ev = at.v0 * ewuv.x + at.v1 * ewuv.y + at.v2 * ewuv.z;
+            if (dot(l, tri_n) > 0.0f) tri_n = tri_n * -1.0f;
+            const float area = length(cross(xyz(q1) - xyz(q0), xyz(q2) - xyz(q0))) / 2.0f;
+            const float cos_theta0 = dot(tri_n, -l);
+            pdf = dist2 / (cos_theta0 * area) / static_cast<float>(f.pc.emissive_triangle_count);
+            const Material emat = load_material(sc.materials, at.mat);
+            Tally uncounted;  // the reference fetches the emitter's texture only for visible samples: k_shadow counts the tap
+            const float4 et = sample_texture(sc, emat.emissive_tex, eu, ev, uncounted);
+            tap_if_visible = emat.emissive_tex != -1 ? 1u : 0u;
+            a_factor = emat.emissive * decode_srgb(emat.emissive_tex, et);
+          }
+        }
+        const vec3 brdf = microfacet_brdf(nrm, view, l, metal, a2, base_color);
+        float4* r = st.req + (static_cast<size_t>(j) * 4u) * st.slot_stride + slot;
+        r[0] = make_float4(l.x, l.y, l.z, limit);
+        r[st.slot_stride] = make_float4(a_factor.x, a_factor.y, a_factor.z, correction);
+        r[2u * static_cast<size_t>(st.slot_stride)] = make_float4(brdf.x, brdf.y, brdf.z, n_dot_l);
+        r[3u * static_cast<size_t>(st.slot_stride)] = make_float4(pdf, ubits(etri), ubits(tap_if_visible), 0.0f);
+        continue;
+      }
+
       Hit sh{kInfinity, 0.0f, 0.0f, kNoHit};
       if (ALL_OPAQUE && kind == 2u) {
         // Any accepted triangle along the ray decides an all-opaque shadow query (Q5), and an
@@ -829,16 +914,23 @@ __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const pt_de
     direct = direct + punctual;    // :537
     direct = direct + area_light;  // :538
     indirect = indirect * occlusion;  // :540
+    if (SPLIT) {
+      shaded = true;
+      deferred_m = indirect;
+      deferred_emission = emission;
+      deferred_origin = shadow_origin;
+    }
 
     if (alpha < 1.0f && transp_steps < kMaxTransparencySteps) {  // main.comp:542-547
       ++transp_steps;
-      color = color + direct * alpha * indirect;
+      if (SPLIT) alpha_factor = alpha;
+      else color = color + direct * alpha * indirect;
       indirect = indirect * (1.0f - alpha);
       next_o = pos + kNormalDelta * ray_dir;
       next_d = ray_dir;
     } else {  // main.comp:549-577
       ++light_steps;
-      color = color + direct * indirect;
+      if (!SPLIT) color = color + direct * indirect;
       const Basis basis = orthogonal_matrix(nrm);  // shared by both samplers (:383, :399)
       float diffuse_pdf, microfacet_pdf;
       const vec3 diffuse_dir = diffuse_sample(nrm, basis, rng, diffuse_pdf);
@@ -861,10 +953,22 @@ __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const pt_de
     path_done = light_steps >= kMaxLightSteps;  // main.comp:512
   }
 
+  if (SPLIT && shaded) {  // k_shadow finishes this vertex: color_in + direct * alpha_factor * deferred_m, then the sample if it ends here
+    float4* h = st.pend + slot;
+    const size_t ss = st.slot_stride;
+    h[0] = make_float4(deferred_emission.x, deferred_emission.y, deferred_emission.z, alpha_factor);
+    h[ss] = make_float4(deferred_m.x, deferred_m.y, deferred_m.z, ubits(path_done ? 1u : 0u));
+    h[2 * ss] = make_float4(deferred_origin.x, deferred_origin.y, deferred_origin.z, 0.0f);
+    h[3 * ss] = make_float4(color_in.x, color_in.y, color_in.z, 0.0f);
+    if (path_done) h[4 * ss] = make_float4(indirect.x, indirect.y, indirect.z, 0.0f);
+  }
+
   if (path_done) {  // end of trace() + next stratum of this pixel, or retire the slot (main():597-612)
-    float4 acc = st.accum[slot];
-    finish_sample(color, indirect, bg_linear, acc, tally);
-    st.accum[slot] = acc;
+    if (!(SPLIT && shaded)) {
+      float4 acc = st.accum[slot];
+      finish_sample(color, indirect, bg_linear, acc, tally);
+      st.accum[slot] = acc;
+    }
     ++sample;
     if (sample < f.sample_end) {
       uint32_t x, y;
@@ -890,26 +994,34 @@ __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const pt_de
   return alive;
 }
 
-#ifndef PT_SHADE_MIN_WAVES
-#define PT_SHADE_MIN_WAVES 3  // waves per SIMD the register allocator must leave room for (measured: DESIGN.md)
+// Waves per SIMD the register allocator must leave room for (measured): LDS-resident
+// scenes are VALU-issue bound and run best with the 168 registers of 3 waves; scenes read from
+// global memory are latency bound and gain more from a 4th wave than they lose to spills.
+#ifndef PT_SHADE_MIN_WAVES_LDS
+#define PT_SHADE_MIN_WAVES_LDS 3
 #endif
+#ifndef PT_SHADE_MIN_WAVES_GLOBAL
+#define PT_SHADE_MIN_WAVES_GLOBAL 4
+#endif
+#define PT_SHADE_MIN_WAVES(in_lds) ((in_lds) ? PT_SHADE_MIN_WAVES_LDS : PT_SHADE_MIN_WAVES_GLOBAL)
 // shade_vertex for every extended ray, then compaction of the survivors into the next queue.
 // Persistent workgroups striding the queue, so the LDS scene copy is staged once per block.
-template <bool IN_LDS, bool ALL_OPAQUE>
-__global__ __launch_bounds__(256, PT_SHADE_MIN_WAVES) void k_shade(pt_dev_scene sc, pt_dev_frame f, pt_dev_state st, uint32_t parity) {
+template <bool IN_LDS, bool ALL_OPAQUE, bool SPLIT>
+__global__ __launch_bounds__(256, PT_SHADE_MIN_WAVES(IN_LDS)) void k_shade(pt_dev_scene sc, pt_dev_frame f, pt_dev_state st, uint32_t parity) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
   const uint32_t n = st.counters[PT_CNT_QUEUE0 + parity];
   Tally tally;   // shading work
   Tally walks;   // the shadow walks' traversal work (reported as the `shadow` slice)
   const uint32_t n_lights = sc.directional_light_count + sc.point_light_count + (f.pc.emissive_triangle_count ? 1u : 0u);
   Tracer tr{};
-  if (n_lights && blockIdx.x * blockDim.x < n) tr = make_tracer<IN_LDS>(sc, lds_dyn);  // block-uniform
+  if (!SPLIT && n_lights && blockIdx.x * blockDim.x < n) tr = make_tracer<IN_LDS>(sc, lds_dyn);  // block-uniform
   const vec3 bg_linear = mk(f.bg_linear[0], f.bg_linear[1], f.bg_linear[2]);
 
   for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {  // block-uniform trip count
     const uint32_t gid = base + threadIdx.x;
     const bool active = gid < n;
-    bool alive = false;  // slot continues with a ray next iteration
+    bool alive = false;   // slot continues with a ray next iteration
+    bool shaded = false;  // SPLIT: slot has a deferred direct-light update for k_shadow
     uint32_t slot = 0;
 
     if (active) {
@@ -924,7 +1036,8 @@ __global__ __launch_bounds__(256, PT_SHADE_MIN_WAVES) void k_shade(pt_dev_scene 
       vec3 ray_dir = mk(0, 0, 0);
       if (hw.x != kNoHit) ray_dir = xyz(st.ray_d[slot]);
       vec3 next_o = mk(0, 0, 0), next_d = mk(0, 0, 0);
-      alive = shade_vertex<IN_LDS, ALL_OPAQUE>(sc, f, st, tr, n_lights, bg_linear, slot, hit, ray_dir, p, next_o, next_d, tally, walks);
+      alive = shade_vertex<IN_LDS, ALL_OPAQUE, SPLIT>(sc, f, st, tr, n_lights, bg_linear, slot, hit, ray_dir, p, next_o, next_d, tally,
+                                                      walks, shaded);
       if (alive) {
         st.ray_o[slot] = make_float4(next_o.x, next_o.y, next_o.z, 0.0f);
         st.ray_d[slot] = make_float4(next_d.x, next_d.y, next_d.z, 0.0f);
@@ -934,10 +1047,83 @@ __global__ __launch_bounds__(256, PT_SHADE_MIN_WAVES) void k_shade(pt_dev_scene 
     }
 
     // queue compaction (the whole block converges here)
-    const AppendSlots at = block_append2(alive, &st.counters[PT_CNT_QUEUE0 + (parity ^ 1u)], false, nullptr);
+    const AppendSlots at = block_append2(alive, &st.counters[PT_CNT_QUEUE0 + (parity ^ 1u)], SPLIT && shaded,
+                                         SPLIT ? &st.counters[PT_CNT_SHADOW] : nullptr);
     if (alive) st.queue[parity ^ 1u][at.a] = slot;
+    if (SPLIT && shaded) st.queue_shadow[at.b] = slot;
   }
   flush_tally(tally, st, PT_K_SHADE);
+  if (!SPLIT) flush_tally(walks, st, PT_K_SHADOW);
+}
+
+// The deferred half of a SPLIT k_shade: the shadow walks of every light sample of every
+// vertex shaded this iteration (ray_scene_intersect_with_transparency, main.comp:306-332),
+// the direct-lighting accumulate (main.comp:536-552) and, where the vertex ended its path,
+// the end of trace() and the NaN filter (main.comp:580-582, 607-612). A lean traversal
+// kernel like k_extend; persistent workgroups striding the shadow queue.
+// occupancy bound measured per variant: the any-hit walk fits 4 waves without help and
+// ran best there; the closest-hit walk with its material/texture fetch gains from being held to 6
+#ifndef PT_SHADOW_MIN_WAVES_OPAQUE
+#define PT_SHADOW_MIN_WAVES_OPAQUE 4
+#endif
+#ifndef PT_SHADOW_MIN_WAVES_ALPHA
+#define PT_SHADOW_MIN_WAVES_ALPHA 6
+#endif
+template <bool ALL_OPAQUE>
+__global__ __launch_bounds__(256, ALL_OPAQUE ? PT_SHADOW_MIN_WAVES_OPAQUE : PT_SHADOW_MIN_WAVES_ALPHA) void k_shadow(pt_dev_scene sc, pt_dev_frame f, pt_dev_state st) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
+  const uint32_t n = st.counters[PT_CNT_SHADOW];
+  Tally walks;
+  const uint32_t n_lights = sc.directional_light_count + sc.point_light_count + (f.pc.emissive_triangle_count ? 1u : 0u);
+  const vec3 bg_linear = mk(f.bg_linear[0], f.bg_linear[1], f.bg_linear[2]);
+  const size_t ss = st.slot_stride;
+  if (blockIdx.x * blockDim.x < n) {  // block-uniform
+    const Tracer tr = make_tracer<false>(sc, lds_dyn);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+      const uint32_t slot = st.queue_shadow[i];
+      const float4* h = st.pend + slot;
+      const float4 h0 = h[0], h1 = h[ss], h2 = h[2 * ss], h3 = h[3 * ss];
+      const vec3 origin = xyz(h2);
+      vec3 punctual = splat(0.0f), area_light = splat(0.0f);
+      for (uint32_t j = 0; j < n_lights; ++j) {
+        const float4* r = st.req + (static_cast<size_t>(j) * 4u) * ss + slot;
+        const float4 r0 = r[0], r1 = r[ss], r2 = r[2 * ss], r3 = r[3 * ss];
+        const vec3 l = xyz(r0);
+        const bool is_area = f.pc.emissive_triangle_count && j + 1 == n_lights;
+        Hit sh{kInfinity, 0.0f, 0.0f, kNoHit};
+        if (ALL_OPAQUE && is_area) {  // the emitter-first shortcut of the fused form
+          ++walks.tests;
+          ray_triangle<false>(tr, origin, l, fbits(r3.y), sh);
+          if (sh.tri != kNoHit) {
+            ++walks.rays;
+            continue;
+          }
+        }
+        const float transparency = shadow_walk<false, ALL_OPAQUE>(sc, tr, origin, l, sh, walks);
+        if (transparency == 0.0f) continue;
+        if (sh.tri != kNoHit && sh.t + r1.w < r0.w) continue;  // main.comp:447 / :487 (never holds for a directional light)
+        walks.taps += fbits(r3.z);
+        const vec3 c = xyz(r1) * transparency * xyz(r2) * r2.w / r3.x;
+        if (is_area) area_light = c;
+        else punctual = punctual + c;
+      }
+      vec3 direct = xyz(h0);          // main.comp:536
+      direct = direct + punctual;     // :537
+      direct = direct + area_light;   // :538
+      const vec3 color = xyz(h3) + direct * h0.w * xyz(h1);  // :545 / :552 (h0.w == 1 for the opaque branch)
+      if (fbits(h1.w) & 1u) {         // the path ended at this vertex: main.comp:580-582, 607-612
+        float4 acc = st.accum[slot];
+        finish_sample(color, xyz(h[4 * ss]), bg_linear, acc, walks);
+        st.accum[slot] = acc;
+      } else {
+        float4 pb = st.path_b[slot];
+        pb.x = color.x;
+        pb.y = color.y;
+        pb.z = color.z;
+        st.path_b[slot] = pb;
+      }
+    }
+  }
   flush_tally(walks, st, PT_K_SHADOW);
 }
 
@@ -949,7 +1135,7 @@ __global__ __launch_bounds__(256, PT_SHADE_MIN_WAVES) void k_shade(pt_dev_scene 
 // last sample ends — runs inside ONE launch, one lane per slot. Same functions, same order
 // per slot, so the results are unchanged.
 template <bool IN_LDS, bool ALL_OPAQUE>
-__global__ __launch_bounds__(256, PT_SHADE_MIN_WAVES) void k_tail(pt_dev_scene sc, pt_dev_frame f, pt_dev_state st, uint32_t parity,
+__global__ __launch_bounds__(256, PT_SHADE_MIN_WAVES(IN_LDS)) void k_tail(pt_dev_scene sc, pt_dev_frame f, pt_dev_state st, uint32_t parity,
                                                                   uint32_t max_vertices) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
   const uint32_t n = st.counters[PT_CNT_QUEUE0 + parity];
@@ -972,7 +1158,8 @@ __global__ __launch_bounds__(256, PT_SHADE_MIN_WAVES) void k_tail(pt_dev_scene s
         if (primary) st.primary_id[slot] = h.tri;
         primary = false;
         vec3 next_o = mk(0, 0, 0), next_d = mk(0, 0, 0);
-        if (!shade_vertex<IN_LDS, ALL_OPAQUE>(sc, f, st, tr, n_lights, bg_linear, slot, h, d, p, next_o, next_d, tally, walks)) break;
+        bool shaded;
+        if (!shade_vertex<IN_LDS, ALL_OPAQUE, false>(sc, f, st, tr, n_lights, bg_linear, slot, h, d, p, next_o, next_d, tally, walks, shaded)) break;
         o = next_o;
         d = next_d;
       }
@@ -1038,17 +1225,30 @@ void launch_extend(const pt_dev_scene& sc, const pt_dev_state& st, uint32_t pari
   else hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(block), trace_lds_bytes(sc, block), s, sc, st, parity);
 }
 
+void launch_shadow(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t max_entries, uint32_t block,
+                   uint32_t max_blocks, hipStream_t s) {
+  uint32_t grid = blocks_for(max_entries, block);
+  if (grid > max_blocks) grid = max_blocks;
+  if (sc.all_opaque) hipLaunchKernelGGL(k_shadow<true>, dim3(grid), dim3(block), trace_lds_bytes(sc, block), s, sc, f, st);
+  else hipLaunchKernelGGL(k_shadow<false>, dim3(grid), dim3(block), trace_lds_bytes(sc, block), s, sc, f, st);
+}
+
 void launch_shade(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity,
-                  uint32_t max_entries, uint32_t block, uint32_t max_blocks, bool has_lights, hipStream_t s) {
+                  uint32_t max_entries, uint32_t block, uint32_t max_blocks, bool has_lights, bool split, hipStream_t s) {
   uint32_t grid = blocks_for(max_entries, block);
   if (grid > max_blocks) grid = max_blocks;
   const size_t lds = has_lights ? trace_lds_bytes(sc, block) : 0;
   const int variant = (sc.scene_in_lds ? 2 : 0) | (sc.all_opaque ? 1 : 0);
+  if (split) {  // global scene with lights: requests out, walks in k_shadow
+    if (sc.all_opaque) hipLaunchKernelGGL((k_shade<false, true, true>), dim3(grid), dim3(block), 0, s, sc, f, st, parity);
+    else hipLaunchKernelGGL((k_shade<false, false, true>), dim3(grid), dim3(block), 0, s, sc, f, st, parity);
+    return;
+  }
   switch (variant) {
-    case 3: hipLaunchKernelGGL((k_shade<true, true>), dim3(grid), dim3(block), lds, s, sc, f, st, parity); break;
-    case 2: hipLaunchKernelGGL((k_shade<true, false>), dim3(grid), dim3(block), lds, s, sc, f, st, parity); break;
-    case 1: hipLaunchKernelGGL((k_shade<false, true>), dim3(grid), dim3(block), lds, s, sc, f, st, parity); break;
-    default: hipLaunchKernelGGL((k_shade<false, false>), dim3(grid), dim3(block), lds, s, sc, f, st, parity); break;
+    case 3: hipLaunchKernelGGL((k_shade<true, true, false>), dim3(grid), dim3(block), lds, s, sc, f, st, parity); break;
+    case 2: hipLaunchKernelGGL((k_shade<true, false, false>), dim3(grid), dim3(block), lds, s, sc, f, st, parity); break;
+    case 1: hipLaunchKernelGGL((k_shade<false, true, false>), dim3(grid), dim3(block), lds, s, sc, f, st, parity); break;
+    default: hipLaunchKernelGGL((k_shade<false, false, false>), dim3(grid), dim3(block), lds, s, sc, f, st, parity); break;
   }
 }
 
