@@ -55,9 +55,10 @@ struct pt_ctx {
   uint32_t band_slots = 0;          // 0 = whole frame in one band
   uint32_t trace_blocks = 0;        // grid cap of k_extend (persistent workgroups striding the queue)
   uint32_t shade_blocks = 0;        // grid cap of k_shade
+  uint32_t compact_every = 16;      // fused pipeline: iterations between queue compactions (PT_COMPACT_EVERY; 1 = every iteration)
   bool split_shadow = true;         // scenes in global memory: shadow walks in their own kernel (PT_SPLIT_SHADOW=0 keeps them in k_shade)
   uint32_t tail_entries = 262144;   // queue length below which the rest of the frame runs in one k_tail launch (0 = never)
-  uint32_t lds_scene_bytes = 12288; // scenes up to this size (pair records + triangle positions) are staged whole in LDS
+  uint32_t lds_scene_bytes = 16384; // scenes up to this size (pair records + triangle positions) are staged whole in LDS
   uint32_t* host_counts = nullptr;  // pinned
   hipEvent_t poll_events[2] = {nullptr, nullptr};
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
@@ -257,6 +258,7 @@ extern "C" pt_ctx* pt_create(int device) {
   if (const char* e = std::getenv("PT_LDS_SCENE_BYTES")) ctx->lds_scene_bytes = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   if (ctx->trace_blocks == 0) ctx->trace_blocks = 2048;
   if (ctx->lds_scene_bytes > 32768) ctx->lds_scene_bytes = 32768;
+  if (const char* e = std::getenv("PT_COMPACT_EVERY")) ctx->compact_every = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   if (const char* e = std::getenv("PT_SPLIT_SHADOW")) ctx->split_shadow = std::strtoul(e, nullptr, 10) != 0;
   if (const char* e = std::getenv("PT_TAIL_ENTRIES")) ctx->tail_entries = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   if (const char* e = std::getenv("PT_BAND_SLOTS")) ctx->band_slots = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
@@ -420,9 +422,13 @@ extern "C" int pt_upload_scene(pt_ctx* ctx, const pt_scene_desc* s) {
   d.point_light_count = s->point_light_count;
   d.stack_entries = depth + 1;
   d.triangle_count = s->triangle_count;
+  d.material_count = s->material_count;
+  d.emissive_count = s->emissive_triangle_count;
   // LDS residency: a scene whose pair records + triangle positions fit in lds_scene_bytes
   // is staged whole in every traversal workgroup's LDS (next to the 1 KiB-per-level stack).
-  d.scene_in_lds = (64ull * d.pair_count + 48ull * s->triangle_count <= ctx->lds_scene_bytes) ? 1u : 0u;
+  d.scene_in_lds = (64ull * d.pair_count + (48ull + 64ull) * s->triangle_count + 64ull * s->material_count +
+                        32ull * (s->directional_light_count + s->point_light_count) + 4ull * s->emissive_triangle_count <=
+                    ctx->lds_scene_bytes) ? 1u : 0u;
   PT_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
   PT_HIP(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors die here
   float ms = 0.0f;
@@ -485,7 +491,9 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
   band_slots = (band_slots + 63u) & ~63u;
   if (band_slots > total_slots) band_slots = total_slots;
   // traversal block size: stack (block * stack_entries words) + the scene copy, kept within 64 KiB
-  const uint32_t scene_lds = sc.scene_in_lds ? 64u * sc.pair_count + 48u * sc.triangle_count : 0u;
+  const uint32_t scene_lds = sc.scene_in_lds ? 64u * sc.pair_count + (48u + 64u) * sc.triangle_count + 64u * sc.material_count +
+                                                   32u * (sc.directional_light_count + sc.point_light_count) + 4u * sc.emissive_count + 16u
+                                             : 0u;
   if (256u * sc.stack_entries * 4u + scene_lds > 65536u) sc.scene_in_lds = 0;  // deep tree: the stack needs the LDS
   const uint32_t trace_block = (256u * sc.stack_entries * 4u <= 65536u) ? 256u : 64u;
   const bool split = ctx->split_shadow && !sc.scene_in_lds && n_lights != 0;
@@ -530,19 +538,25 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
 
     uint32_t bound = f.slot_count;  // live entries never increase: the last polled count bounds every later queue
     uint64_t iter = 0;
+    uint32_t parity = 0;  // the queue the next iteration reads
     int poll = 0;
     bool have_prev = false;
     bool drained = (f.sample_begin == f.sample_end);
     while (!drained && iter < max_iters) {
       for (uint32_t b = 0; b < kBatch; ++b, ++iter) {
-        const uint32_t parity = static_cast<uint32_t>(iter & 1u);
+        // the queue is rebuilt on the last iteration of a batch (every iteration in the split pipeline,
+        // whose shadow queue is an append anyway) and re-used as it stands in between
+        const bool compact = split || ctx->compact_every <= 1 || (b + 1) % ctx->compact_every == 0 || b + 1 == kBatch;
         timed(PT_K_EXTEND, [&] { ptd::launch_extend(sc, st, parity, bound, trace_block, ctx->trace_blocks, stream); });
-        timed(PT_K_SHADE, [&] { ptd::launch_shade(sc, f, st, parity, bound, trace_block, ctx->shade_blocks, n_lights != 0, split, stream); });
+        timed(PT_K_SHADE, [&] {
+          ptd::launch_shade(sc, f, st, parity, bound, trace_block, ctx->shade_blocks, n_lights != 0, split, compact, stream);
+        });
         if (split) timed(PT_K_SHADOW, [&] { ptd::launch_shadow(sc, f, st, bound, trace_block, ctx->trace_blocks, stream); });
+        if (compact) parity ^= 1u;
       }
       PT_HIP(ctx, hipGetLastError());
       // entries queued for the NEXT iteration; stays intact until that iteration's successor recycles it
-      PT_HIP(ctx, hipMemcpyAsync(&ctx->host_counts[poll], st.counters + PT_CNT_QUEUE0 + (iter & 1u), sizeof(uint32_t),
+      PT_HIP(ctx, hipMemcpyAsync(&ctx->host_counts[poll], st.counters + PT_CNT_QUEUE0 + parity, sizeof(uint32_t),
                                  hipMemcpyDeviceToHost, stream));
       PT_HIP(ctx, hipEventRecord(ctx->poll_events[poll], stream));
       if (have_prev) {  // look at the previous batch while this one runs: the GPU never waits for the host
@@ -555,7 +569,6 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
       poll ^= 1;
       if (!drained && bound <= ctx->tail_entries) {
         // short queue: every remaining vertex of every queued slot in one launch (k_tail)
-        const uint32_t parity = static_cast<uint32_t>(iter & 1u);
         const uint32_t max_vertices = static_cast<uint32_t>(max_iters > 0xFFFFFFFFull ? 0xFFFFFFFFull : max_iters);
         timed(PT_K_TAIL, [&] { ptd::launch_tail(sc, f, st, parity, bound, trace_block, max_vertices, stream); });
         PT_HIP(ctx, hipGetLastError());

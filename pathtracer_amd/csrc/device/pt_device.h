@@ -39,9 +39,11 @@ struct pt_dev_scene {
   uint32_t point_light_count;
   uint32_t stack_entries;            // LDS stack rows per lane (bvh_max_depth + 1)
   uint32_t triangle_count;
+  uint32_t material_count;
+  uint32_t emissive_count;
   uint32_t pair_count;
   uint32_t root_ref, root_cnt;       // the root as a child reference: pair 0 (count 0) or a leaf's triangle range
-  uint32_t scene_in_lds;             // 1: pair records + triangle positions are staged whole in every traversal workgroup's LDS
+  uint32_t scene_in_lds;             // 1: the scene (pair records, triangle positions; for shading also attributes, materials, lights, emitter list) is staged whole in the workgroup's LDS
   uint32_t all_opaque;               // 1: no surface can report alpha != 1 (shadow rays may stop at the first hit)
 };
 
@@ -82,7 +84,8 @@ void launch_init(const pt_dev_frame& f, const pt_dev_state& st, hipStream_t s);
 void launch_extend(const pt_dev_scene& sc, const pt_dev_state& st, uint32_t parity, uint32_t max_entries, uint32_t block,
                    uint32_t max_blocks, hipStream_t s);
 void launch_shade(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity,
-                  uint32_t max_entries, uint32_t block, uint32_t max_blocks, bool has_lights, bool split, hipStream_t s);
+                  uint32_t max_entries, uint32_t block, uint32_t max_blocks, bool has_lights, bool split, bool compact,
+                  hipStream_t s);
 void launch_shadow(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t max_entries, uint32_t block,
                    uint32_t max_blocks, hipStream_t s);
 void launch_tail(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity, uint32_t max_entries,

@@ -82,6 +82,19 @@ struct AppendSlots {
   uint32_t a, b;
 };
 __device__ __forceinline__ AppendSlots block_append2(bool pred_a, uint32_t* counter_a, bool pred_b, uint32_t* counter_b) {
+#ifdef PT_EXP_WAVE_APPEND  // experiment: one atomic per wave, no barrier
+  {
+    const uint64_t ma = __ballot(pred_a), mb = __ballot(pred_b);
+    uint32_t base_a = 0, base_b = 0;
+    if (lane_id() == 0) {
+      if (ma && counter_a) base_a = atomicAdd(counter_a, static_cast<uint32_t>(__popcll(ma)));
+      if (mb && counter_b) base_b = atomicAdd(counter_b, static_cast<uint32_t>(__popcll(mb)));
+    }
+    base_a = __builtin_amdgcn_readfirstlane(base_a);
+    base_b = __builtin_amdgcn_readfirstlane(base_b);
+    return AppendSlots{base_a + mbcnt(ma), base_b + mbcnt(mb)};
+  }
+#endif
   __shared__ uint32_t wave_count[2][4];
   __shared__ uint32_t block_base[2];
   const uint64_t mask_a = __ballot(pred_a), mask_b = __ballot(pred_b);
@@ -374,6 +387,57 @@ __device__ __forceinline__ Tracer make_tracer(const pt_dev_scene& sc, uint32_t* 
   return tr;
 }
 
+// What shading reads besides the texel pool. For LDS-resident scenes these arrays are staged
+// next to the traversal data: with them in global memory a vertex cost four more levels of
+// dependent loads (attributes -> material -> emitter index -> emitter position) that the
+// three waves per SIMD of the shading kernel could not hide (48 % VALU busy, profiles/r01c).
+struct ShadeData {
+  const float4* tri_pos;
+  const float4* tri_attr;
+  const float4* materials;
+  const float4* dlights;
+  const float4* plights;
+  const uint32_t* emissive;
+};
+
+__host__ __device__ __forceinline__ uint32_t shade_lds_float4s(const pt_dev_scene& sc) {
+  return 4u * sc.triangle_count + 4u * sc.material_count + 2u * (sc.directional_light_count + sc.point_light_count) +
+         (sc.emissive_count + 3u) / 4u;
+}
+
+template <bool IN_LDS>
+__device__ __forceinline__ ShadeData make_shade_data(const pt_dev_scene& sc, const Tracer& tr, uint32_t* lds) {
+  ShadeData sd{sc.tri_pos, sc.tri_attr, sc.materials, sc.directional_lights, sc.point_lights, sc.emissive_triangles};
+  if (IN_LDS) {  // after make_tracer's [stack | pairs | triangles]
+    float4* attr = reinterpret_cast<float4*>(lds + static_cast<size_t>(blockDim.x) * sc.stack_entries) +
+                   4 * static_cast<size_t>(sc.pair_count) + 3 * static_cast<size_t>(sc.triangle_count);
+    float4* mats = attr + 4 * static_cast<size_t>(sc.triangle_count);
+    float4* dl = mats + 4 * static_cast<size_t>(sc.material_count);
+    float4* pl = dl + 2 * static_cast<size_t>(sc.directional_light_count);
+    uint32_t* em = reinterpret_cast<uint32_t*>(pl + 2 * static_cast<size_t>(sc.point_light_count));
+    for (uint32_t i = threadIdx.x; i < 4u * sc.triangle_count; i += blockDim.x) attr[i] = sc.tri_attr[i];
+    for (uint32_t i = threadIdx.x; i < 4u * sc.material_count; i += blockDim.x) mats[i] = sc.materials[i];
+    for (uint32_t i = threadIdx.x; i < 2u * sc.directional_light_count; i += blockDim.x) dl[i] = sc.directional_lights[i];
+    for (uint32_t i = threadIdx.x; i < 2u * sc.point_light_count; i += blockDim.x) pl[i] = sc.point_lights[i];
+    for (uint32_t i = threadIdx.x; i < sc.emissive_count; i += blockDim.x) em[i] = sc.emissive_triangles[i];
+    __syncthreads();
+    sd = ShadeData{tr.tri_pos, attr, mats, dl, pl, em};
+  }
+  return sd;
+}
+
+template <bool IN_LDS>
+__device__ __forceinline__ uint32_t fetch32(const uint32_t* base, uint32_t index) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (IN_LDS) {
+    typedef const __attribute__((address_space(3))) uint32_t lds_u32;
+    lds_u32* p = (lds_u32*)(uintptr_t)static_cast<uint32_t>(reinterpret_cast<uintptr_t>(base));
+    return p[index];
+  }
+#endif
+  return base[index];
+}
+
 // ---------------------------------------------------------------- scene fetch
 struct TriAttr {  // 64-byte attribute record: normals, uvs, material of one triangle
   vec3 n0, n1, n2;
@@ -381,9 +445,10 @@ struct TriAttr {  // 64-byte attribute record: normals, uvs, material of one tri
   uint32_t mat;
 };
 
-__device__ __forceinline__ TriAttr load_attr(const float4* __restrict__ tri_attr, uint32_t tri) {
-  const float4* p = tri_attr + 4 * static_cast<size_t>(tri);
-  const float4 a = p[0], b = p[1], c = p[2], e = p[3];
+template <bool IN_LDS>
+__device__ __forceinline__ TriAttr load_attr(const float4* tri_attr, uint32_t tri) {
+  const float4 a = fetch16<IN_LDS>(tri_attr, 4 * tri), b = fetch16<IN_LDS>(tri_attr, 4 * tri + 1);
+  const float4 c = fetch16<IN_LDS>(tri_attr, 4 * tri + 2), e = fetch16<IN_LDS>(tri_attr, 4 * tri + 3);
   TriAttr r;
   r.n0 = mk(a.x, a.y, a.z);
   r.n1 = mk(a.w, b.x, b.y);
@@ -405,9 +470,10 @@ struct Material {  // main.comp:42-58
   int emissive_tex;
 };
 
-__device__ __forceinline__ Material load_material(const float4* __restrict__ mats, uint32_t idx) {
-  const float4* p = mats + 4 * static_cast<size_t>(idx);
-  const float4 a = p[0], b = p[1], c = p[2], e = p[3];
+template <bool IN_LDS>
+__device__ __forceinline__ Material load_material(const float4* mats, uint32_t idx) {
+  const float4 a = fetch16<IN_LDS>(mats, 4 * idx), b = fetch16<IN_LDS>(mats, 4 * idx + 1);
+  const float4 c = fetch16<IN_LDS>(mats, 4 * idx + 2), e = fetch16<IN_LDS>(mats, 4 * idx + 3);
   Material m;
   m.base_color = a;
   m.base_tex = static_cast<int>(fbits(b.x));
@@ -480,13 +546,14 @@ __device__ __forceinline__ vec3 decode_srgb(int tex_index, const float4& s) {
 }
 
 // get_interpolated_data without the normal (the shadow walk never reads it), main.comp:226-240
-__device__ __forceinline__ void interpolate_pos_uv(const pt_dev_scene& sc, uint32_t tri, vec3 wuv, vec3& pos,
+template <bool IN_LDS>
+__device__ __forceinline__ void interpolate_pos_uv(const ShadeData& sd, uint32_t tri, vec3 wuv, vec3& pos,
                                                    float& tu, float& tv, uint32_t& mat, vec3* normal, Tally& tally) {
   ++tally.hits;
-  const float4 q0 = sc.tri_pos[3 * static_cast<size_t>(tri)];
-  const float4 q1 = sc.tri_pos[3 * static_cast<size_t>(tri) + 1];
-  const float4 q2 = sc.tri_pos[3 * static_cast<size_t>(tri) + 2];
-  const TriAttr at = load_attr(sc.tri_attr, tri);
+  const float4 q0 = fetch16<IN_LDS>(sd.tri_pos, 3 * tri);
+  const float4 q1 = fetch16<IN_LDS>(sd.tri_pos, 3 * tri + 1);
+  const float4 q2 = fetch16<IN_LDS>(sd.tri_pos, 3 * tri + 2);
+  const TriAttr at = load_attr<IN_LDS>(sd.tri_attr, tri);
   pos = mat3_mul(xyz(q0), xyz(q1), xyz(q2), wuv);
   if (normal) *normal = normalize(mat3_mul(at.n0, at.n1, at.n2, wuv));
   tu = at.u0 * wuv.x + at.u1 * wuv.y + at.u2 * wuv.z;
@@ -665,7 +732,9 @@ __global__ __launch_bounds__(256) void k_extend(pt_dev_scene sc, pt_dev_state st
     const Tracer tr = make_tracer<IN_LDS>(sc, lds_dyn);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
       const uint32_t slot = st.queue[parity][i];
-      const float4 o4 = st.ray_o[slot], d4 = st.ray_d[slot];
+      const float4 d4 = st.ray_d[slot];
+      if (d4.w != 0.0f) continue;  // retired since the queue was last compacted
+      const float4 o4 = st.ray_o[slot];
       Hit h{kInfinity, 0.0f, 0.0f, kNoHit};
       traverse<IN_LDS, false>(tr, xyz(o4), xyz(d4), h, tally);
       st.hit[slot] = make_uint4(h.tri, fbits(h.u), fbits(h.v), fbits(h.t));
@@ -677,8 +746,8 @@ __global__ __launch_bounds__(256) void k_extend(pt_dev_scene sc, pt_dev_state st
 // ray_scene_intersect_with_transparency, main.comp:306-332. Returns the transparency and
 // leaves the last traversal's result in h.
 template <bool IN_LDS, bool ALL_OPAQUE>
-__device__ __forceinline__ float shadow_walk(const pt_dev_scene& sc, const Tracer& tr, vec3 origin, vec3 dir, Hit& h,
-                                             Tally& tally) {
+__device__ __forceinline__ float shadow_walk(const pt_dev_scene& sc, const ShadeData& sd, const Tracer& tr, vec3 origin, vec3 dir,
+                                             Hit& h, Tally& tally) {
   float transparency = 1.0f;
 #ifdef PT_EXP_NO_SHADOW  // timing experiment only: skip the walk (wrong images)
   return transparency;
@@ -698,9 +767,9 @@ __device__ __forceinline__ float shadow_walk(const pt_dev_scene& sc, const Trace
     vec3 pos;
     float tu, tv;
     uint32_t mat_idx;
-    interpolate_pos_uv(sc, h.tri, wuv, pos, tu, tv, mat_idx, nullptr, tally);
-    const float4 base = sc.materials[4 * static_cast<size_t>(mat_idx)];
-    const int base_tex = static_cast<int>(fbits(sc.materials[4 * static_cast<size_t>(mat_idx) + 1].x));
+    interpolate_pos_uv<IN_LDS>(sd, h.tri, wuv, pos, tu, tv, mat_idx, nullptr, tally);
+    const float4 base = fetch16<IN_LDS>(sd.materials, 4 * mat_idx);
+    const int base_tex = static_cast<int>(fbits(fetch16<IN_LDS>(sd.materials, 4 * mat_idx + 1).x));
     const float alpha = base.w * sample_texture(sc, base_tex, tu, tv, tally).w;
     if (alpha == 1.0f) return 0.0f;  // any opaque closest hit, at any distance (Q5)
     transparency *= 1.0f - alpha;
@@ -731,7 +800,7 @@ struct PathRegs {
 // caller to queue the slot for k_shadow. The deferred arithmetic is the same expressions in
 // the same order, so results stay bit-identical to the fused form.
 template <bool IN_LDS, bool ALL_OPAQUE, bool SPLIT>
-__device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st,
+__device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const ShadeData& sd, const pt_dev_frame& f, const pt_dev_state& st,
                                              const Tracer& tr, uint32_t n_lights, vec3 bg_linear, uint32_t slot,
                                              const Hit& hit, vec3 ray_dir, PathRegs& p, vec3& next_o, vec3& next_d,
                                              Tally& tally, Tally& walks, bool& shaded) {
@@ -751,11 +820,11 @@ __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const pt_de
     vec3 pos, nrm;
     float tu, tv;
     uint32_t mat_idx;
-    interpolate_pos_uv(sc, hit.tri, wuv, pos, tu, tv, mat_idx, &nrm, tally);
+    interpolate_pos_uv<IN_LDS>(sd, hit.tri, wuv, pos, tu, tv, mat_idx, &nrm, tally);
     if (dot(nrm, ray_dir) > 0.0f) nrm = nrm * -1.0f;  // main.comp:524
 
     // get_material_data, main.comp:242-259
-    const Material m = load_material(sc.materials, mat_idx);
+    const Material m = load_material<IN_LDS>(sd.materials, mat_idx);
     const float4 bc = sample_texture(sc, m.base_tex, tu, tv, tally);
     const vec3 base_color = mk(m.base_color.x, m.base_color.y, m.base_color.z) * decode_srgb(m.base_tex, bc);
     const float alpha = m.base_color.w * bc.w;
@@ -790,12 +859,12 @@ __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const pt_de
       float4 q0 = l0, q1 = l0, q2 = l0;
       const uint32_t kind = j < n_dir ? 0u : (j < n_punctual ? 1u : 2u);
       if (kind == 0u) {
-        l0 = sc.directional_lights[2 * j];
-        l = -xyz(sc.directional_lights[2 * j + 1]);
+        l0 = fetch16<IN_LDS>(sd.dlights, 2 * j);
+        l = -xyz(fetch16<IN_LDS>(sd.dlights, 2 * j + 1));
       } else if (kind == 1u) {
         const uint32_t i = j - n_dir;
-        l0 = sc.point_lights[2 * i];
-        const vec3 lpos = xyz(sc.point_lights[2 * i + 1]);
+        l0 = fetch16<IN_LDS>(sd.plights, 2 * i);
+        const vec3 lpos = xyz(fetch16<IN_LDS>(sd.plights, 2 * i + 1));
         sample_dir = uniform_hemisphere_sampling(normalize(pos - lpos), rng);
         sample_pos = lpos + sample_dir * kPointLightRadius;
         l = sample_pos - pos;
@@ -805,7 +874,7 @@ __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const pt_de
         const uint32_t count = f.pc.emissive_triangle_count;
         uint32_t pick = static_cast<uint32_t>(rand_float(rng) * static_cast<float>(count));
         if (pick > count - 1) pick = count - 1;  // Q3: rand_float may be exactly 1.0
-        etri = sc.emissive_triangles[pick];
+        etri = fetch32<IN_LDS>(sd.emissive, pick);
         float su = rand_float(rng), sv = rand_float(rng);  // sample_triangle, main.comp:158-165
         if (su + sv > 1.0f) {
           su = 1.0f - su;
@@ -815,9 +884,9 @@ __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const pt_de
         // get_interpolated_data of the emitter; its normal, uv and material are only needed
         // if the walk lets the sample through, so only the position is formed here
         ++tally.hits;
-        q0 = sc.tri_pos[3 * static_cast<size_t>(etri)];
-        q1 = sc.tri_pos[3 * static_cast<size_t>(etri) + 1];
-        q2 = sc.tri_pos[3 * static_cast<size_t>(etri) + 2];
+        q0 = fetch16<IN_LDS>(sd.tri_pos, 3 * etri);
+        q1 = fetch16<IN_LDS>(sd.tri_pos, 3 * etri + 1);
+        q2 = fetch16<IN_LDS>(sd.tri_pos, 3 * etri + 2);
         sample_pos = mat3_mul(xyz(q0), xyz(q1), xyz(q2), ewuv);
         l = sample_pos - pos;
         dist2 = dot(l, l);
@@ -840,7 +909,7 @@ __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const pt_de
             const float cos_theta0 = dot(sample_dir, -l);
             pdf = dist2 / (cos_theta0 * kLightArea);
           } else {
-            const TriAttr at = load_attr(sc.tri_attr, etri);
+            const TriAttr at = load_attr<IN_LDS>(sd.tri_attr, etri);
             vec3 tri_n = normalize(mat3_mul(at.n0, at.n1, at.n2, ewuv));
             const float eu = at.u0 * ewuv.x + at.u1 * ewuv.y + at.u2 * ewuv.z;
             const float ev = at.v0 * ewuv.x + at.v1 * ewuv.y + at.v2 * ewuv.z;
@@ -848,7 +917,7 @@ __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const pt_de
             const float area = length(cross(xyz(q1) - xyz(q0), xyz(q2) - xyz(q0))) / 2.0f;
             const float cos_theta0 = dot(tri_n, -l);
             pdf = dist2 / (cos_theta0 * area) / static_cast<float>(f.pc.emissive_triangle_count);
-            const Material emat = load_material(sc.materials, at.mat);
+            const Material emat = load_material<IN_LDS>(sd.materials, at.mat);
             Tally uncounted;  // the reference fetches the emitter's texture only for visible samples: k_shadow counts the tap
             const float4 et = sample_texture(sc, emat.emissive_tex, eu, ev, uncounted);
             tap_if_visible = emat.emissive_tex != -1 ? 1u : 0u;
@@ -877,7 +946,7 @@ __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const pt_de
           continue;
         }
       }
-      const float transparency = shadow_walk<IN_LDS, ALL_OPAQUE>(sc, tr, shadow_origin, l, sh, walks);
+      const float transparency = shadow_walk<IN_LDS, ALL_OPAQUE>(sc, sd, tr, shadow_origin, l, sh, walks);
       if (transparency == 0.0f) continue;
       if (kind != 0u) {
         const float correction = kNormalDelta / dot(l, nrm);
@@ -894,7 +963,7 @@ __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const pt_de
         const float n_dot_l = __builtin_fabsf(dot(nrm, l));
         punctual = punctual + radiance * microfacet_brdf(nrm, view, l, metal, a2, base_color) * n_dot_l / pdf;
       } else {
-        const TriAttr at = load_attr(sc.tri_attr, etri);
+        const TriAttr at = load_attr<IN_LDS>(sd.tri_attr, etri);
         vec3 tri_n = normalize(mat3_mul(at.n0, at.n1, at.n2, ewuv));
         const float eu = at.u0 * ewuv.x + at.u1 * ewuv.y + at.u2 * ewuv.z;
         const float ev = at.v0 * ewuv.x + at.v1 * ewuv.y + at.v2 * ewuv.z;
@@ -903,7 +972,7 @@ __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const pt_de
         const float cos_theta0 = dot(tri_n, -l);
         const float pdf = dist2 / (cos_theta0 * area) / static_cast<float>(f.pc.emissive_triangle_count);
         const float n_dot_l = __builtin_fabsf(dot(nrm, l));
-        const Material emat = load_material(sc.materials, at.mat);
+        const Material emat = load_material<IN_LDS>(sd.materials, at.mat);
         const float4 et = sample_texture(sc, emat.emissive_tex, eu, ev, tally);
         const vec3 e_emission = emat.emissive * decode_srgb(emat.emissive_tex, et) * transparency;
         area_light = e_emission * microfacet_brdf(nrm, view, l, metal, a2, base_color) * n_dot_l / pdf;
@@ -1007,14 +1076,19 @@ __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const pt_de
 // shade_vertex for every extended ray, then compaction of the survivors into the next queue.
 // Persistent workgroups striding the queue, so the LDS scene copy is staged once per block.
 template <bool IN_LDS, bool ALL_OPAQUE, bool SPLIT>
-__global__ __launch_bounds__(256, PT_SHADE_MIN_WAVES(IN_LDS)) void k_shade(pt_dev_scene sc, pt_dev_frame f, pt_dev_state st, uint32_t parity) {
+__global__ __launch_bounds__(256, PT_SHADE_MIN_WAVES(IN_LDS)) void k_shade(pt_dev_scene sc, pt_dev_frame f, pt_dev_state st, uint32_t parity,
+                                                                             uint32_t compact) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
   const uint32_t n = st.counters[PT_CNT_QUEUE0 + parity];
   Tally tally;   // shading work
   Tally walks;   // the shadow walks' traversal work (reported as the `shadow` slice)
   const uint32_t n_lights = sc.directional_light_count + sc.point_light_count + (f.pc.emissive_triangle_count ? 1u : 0u);
   Tracer tr{};
-  if (!SPLIT && n_lights && blockIdx.x * blockDim.x < n) tr = make_tracer<IN_LDS>(sc, lds_dyn);  // block-uniform
+  ShadeData sd{sc.tri_pos, sc.tri_attr, sc.materials, sc.directional_lights, sc.point_lights, sc.emissive_triangles};
+  if (blockIdx.x * blockDim.x < n) {  // block-uniform
+    if (IN_LDS || (!SPLIT && n_lights)) tr = make_tracer<IN_LDS>(sc, lds_dyn);
+    sd = make_shade_data<IN_LDS>(sc, tr, lds_dyn);
+  }
   const vec3 bg_linear = mk(f.bg_linear[0], f.bg_linear[1], f.bg_linear[2]);
 
   for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {  // block-uniform trip count
@@ -1024,11 +1098,16 @@ __global__ __launch_bounds__(256, PT_SHADE_MIN_WAVES(IN_LDS)) void k_shade(pt_de
     bool shaded = false;  // SPLIT: slot has a deferred direct-light update for k_shadow
     uint32_t slot = 0;
 
+    float4 pb = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    bool live = false;  // not retired since the queue was last compacted
     if (active) {
       slot = st.queue[parity][gid];
+      pb = st.path_b[slot];
+      live = ctr_sample(fbits(pb.w)) < f.sample_end;
+    }
+    if (live) {
       const uint4 hw = st.hit[slot];
       const float4 pa = st.path_a[slot];
-      const float4 pb = st.path_b[slot];
       const uint32_t ctr = fbits(pb.w);
       PathRegs p{xyz(pa), xyz(pb), fbits(pa.w), ctr_light(ctr), ctr_transp(ctr), ctr_sample(ctr)};
       if (ctr_primary(ctr)) st.primary_id[slot] = hw.x;
@@ -1036,21 +1115,28 @@ __global__ __launch_bounds__(256, PT_SHADE_MIN_WAVES(IN_LDS)) void k_shade(pt_de
       vec3 ray_dir = mk(0, 0, 0);
       if (hw.x != kNoHit) ray_dir = xyz(st.ray_d[slot]);
       vec3 next_o = mk(0, 0, 0), next_d = mk(0, 0, 0);
-      alive = shade_vertex<IN_LDS, ALL_OPAQUE, SPLIT>(sc, f, st, tr, n_lights, bg_linear, slot, hit, ray_dir, p, next_o, next_d, tally,
+      alive = shade_vertex<IN_LDS, ALL_OPAQUE, SPLIT>(sc, sd, f, st, tr, n_lights, bg_linear, slot, hit, ray_dir, p, next_o, next_d, tally,
                                                       walks, shaded);
       if (alive) {
         st.ray_o[slot] = make_float4(next_o.x, next_o.y, next_o.z, 0.0f);
         st.ray_d[slot] = make_float4(next_d.x, next_d.y, next_d.z, 0.0f);
+      } else {
+        st.ray_d[slot] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);  // retired: k_extend skips the slot until the next compaction drops it
       }
       st.path_a[slot] = make_float4(p.indirect.x, p.indirect.y, p.indirect.z, ubits(p.rng));
       st.path_b[slot] = make_float4(p.color.x, p.color.y, p.color.z, ubits(ctr_pack(p.light_steps, p.transp_steps, false, p.sample)));
     }
 
-    // queue compaction (the whole block converges here)
-    const AppendSlots at = block_append2(alive, &st.counters[PT_CNT_QUEUE0 + (parity ^ 1u)], SPLIT && shaded,
-                                         SPLIT ? &st.counters[PT_CNT_SHADOW] : nullptr);
-    if (alive) st.queue[parity ^ 1u][at.a] = slot;
-    if (SPLIT && shaded) st.queue_shadow[at.b] = slot;
+    // Queue compaction (the whole block converges here). A slot leaves the queue only when its
+    // pixel has run all its samples, so the queue changes slowly: it is rebuilt on the
+    // iterations the host marks (`compact`, block-uniform) and re-used as it stands in between
+    // — no barrier, no atomic, no queue write on those iterations; retired slots idle.
+    if (compact) {
+      const AppendSlots at = block_append2(alive, &st.counters[PT_CNT_QUEUE0 + (parity ^ 1u)], SPLIT && shaded,
+                                           SPLIT ? &st.counters[PT_CNT_SHADOW] : nullptr);
+      if (alive) st.queue[parity ^ 1u][at.a] = slot;
+      if (SPLIT && shaded) st.queue_shadow[at.b] = slot;
+    }
   }
   flush_tally(tally, st, PT_K_SHADE);
   if (!SPLIT) flush_tally(walks, st, PT_K_SHADOW);
@@ -1079,6 +1165,7 @@ __global__ __launch_bounds__(256, ALL_OPAQUE ? PT_SHADOW_MIN_WAVES_OPAQUE : PT_S
   const size_t ss = st.slot_stride;
   if (blockIdx.x * blockDim.x < n) {  // block-uniform
     const Tracer tr = make_tracer<false>(sc, lds_dyn);
+    const ShadeData sd = make_shade_data<false>(sc, tr, lds_dyn);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
       const uint32_t slot = st.queue_shadow[i];
       const float4* h = st.pend + slot;
@@ -1099,7 +1186,7 @@ __global__ __launch_bounds__(256, ALL_OPAQUE ? PT_SHADOW_MIN_WAVES_OPAQUE : PT_S
             continue;
           }
         }
-        const float transparency = shadow_walk<false, ALL_OPAQUE>(sc, tr, origin, l, sh, walks);
+        const float transparency = shadow_walk<false, ALL_OPAQUE>(sc, sd, tr, origin, l, sh, walks);
         if (transparency == 0.0f) continue;
         if (sh.tri != kNoHit && sh.t + r1.w < r0.w) continue;  // main.comp:447 / :487 (never holds for a directional light)
         walks.taps += fbits(r3.z);
@@ -1144,6 +1231,7 @@ __global__ __launch_bounds__(256, PT_SHADE_MIN_WAVES(IN_LDS)) void k_tail(pt_dev
   const vec3 bg_linear = mk(f.bg_linear[0], f.bg_linear[1], f.bg_linear[2]);
   if (blockIdx.x * blockDim.x < n) {  // block-uniform
     const Tracer tr = make_tracer<IN_LDS>(sc, lds_dyn);
+    const ShadeData sd = make_shade_data<IN_LDS>(sc, tr, lds_dyn);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
       const uint32_t slot = st.queue[parity][i];
       const float4 o4 = st.ray_o[slot], d4 = st.ray_d[slot];
@@ -1159,7 +1247,7 @@ __global__ __launch_bounds__(256, PT_SHADE_MIN_WAVES(IN_LDS)) void k_tail(pt_dev
         primary = false;
         vec3 next_o = mk(0, 0, 0), next_d = mk(0, 0, 0);
         bool shaded;
-        if (!shade_vertex<IN_LDS, ALL_OPAQUE, false>(sc, f, st, tr, n_lights, bg_linear, slot, h, d, p, next_o, next_d, tally, walks, shaded)) break;
+        if (!shade_vertex<IN_LDS, ALL_OPAQUE, false>(sc, sd, f, st, tr, n_lights, bg_linear, slot, h, d, p, next_o, next_d, tally, walks, shaded)) break;
         o = next_o;
         d = next_d;
       }
@@ -1217,6 +1305,10 @@ static inline size_t trace_lds_bytes(const pt_dev_scene& sc, uint32_t block) {
          (sc.scene_in_lds ? 64u * static_cast<size_t>(sc.pair_count) + 48u * static_cast<size_t>(sc.triangle_count) : 0u);
 }
 
+static inline size_t shade_lds_bytes(const pt_dev_scene& sc, uint32_t block) {
+  return trace_lds_bytes(sc, block) + (sc.scene_in_lds ? 16u * static_cast<size_t>(shade_lds_float4s(sc)) : 0u);
+}
+
 void launch_extend(const pt_dev_scene& sc, const pt_dev_state& st, uint32_t parity, uint32_t max_entries, uint32_t block,
                    uint32_t max_blocks, hipStream_t s) {
   uint32_t grid = blocks_for(max_entries, block);
@@ -1234,28 +1326,29 @@ void launch_shadow(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_s
 }
 
 void launch_shade(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity,
-                  uint32_t max_entries, uint32_t block, uint32_t max_blocks, bool has_lights, bool split, hipStream_t s) {
+                  uint32_t max_entries, uint32_t block, uint32_t max_blocks, bool has_lights, bool split, bool compact,
+                  hipStream_t s) {
   uint32_t grid = blocks_for(max_entries, block);
   if (grid > max_blocks) grid = max_blocks;
-  const size_t lds = has_lights ? trace_lds_bytes(sc, block) : 0;
+  const size_t lds = (has_lights || sc.scene_in_lds) ? shade_lds_bytes(sc, block) : 0;
   const int variant = (sc.scene_in_lds ? 2 : 0) | (sc.all_opaque ? 1 : 0);
   if (split) {  // global scene with lights: requests out, walks in k_shadow
-    if (sc.all_opaque) hipLaunchKernelGGL((k_shade<false, true, true>), dim3(grid), dim3(block), 0, s, sc, f, st, parity);
-    else hipLaunchKernelGGL((k_shade<false, false, true>), dim3(grid), dim3(block), 0, s, sc, f, st, parity);
+    if (sc.all_opaque) hipLaunchKernelGGL((k_shade<false, true, true>), dim3(grid), dim3(block), 0, s, sc, f, st, parity, compact ? 1u : 0u);
+    else hipLaunchKernelGGL((k_shade<false, false, true>), dim3(grid), dim3(block), 0, s, sc, f, st, parity, compact ? 1u : 0u);
     return;
   }
   switch (variant) {
-    case 3: hipLaunchKernelGGL((k_shade<true, true, false>), dim3(grid), dim3(block), lds, s, sc, f, st, parity); break;
-    case 2: hipLaunchKernelGGL((k_shade<true, false, false>), dim3(grid), dim3(block), lds, s, sc, f, st, parity); break;
-    case 1: hipLaunchKernelGGL((k_shade<false, true, false>), dim3(grid), dim3(block), lds, s, sc, f, st, parity); break;
-    default: hipLaunchKernelGGL((k_shade<false, false, false>), dim3(grid), dim3(block), lds, s, sc, f, st, parity); break;
+    case 3: hipLaunchKernelGGL((k_shade<true, true, false>), dim3(grid), dim3(block), lds, s, sc, f, st, parity, compact ? 1u : 0u); break;
+    case 2: hipLaunchKernelGGL((k_shade<true, false, false>), dim3(grid), dim3(block), lds, s, sc, f, st, parity, compact ? 1u : 0u); break;
+    case 1: hipLaunchKernelGGL((k_shade<false, true, false>), dim3(grid), dim3(block), lds, s, sc, f, st, parity, compact ? 1u : 0u); break;
+    default: hipLaunchKernelGGL((k_shade<false, false, false>), dim3(grid), dim3(block), lds, s, sc, f, st, parity, compact ? 1u : 0u); break;
   }
 }
 
 void launch_tail(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity, uint32_t max_entries,
                  uint32_t block, uint32_t max_vertices, hipStream_t s) {
   const uint32_t grid = blocks_for(max_entries, block);
-  const size_t lds = trace_lds_bytes(sc, block);
+  const size_t lds = shade_lds_bytes(sc, block);
   const int variant = (sc.scene_in_lds ? 2 : 0) | (sc.all_opaque ? 1 : 0);
   switch (variant) {
     case 3: hipLaunchKernelGGL((k_tail<true, true>), dim3(grid), dim3(block), lds, s, sc, f, st, parity, max_vertices); break;
