@@ -46,7 +46,7 @@ def kernel_roofline(name: str, ks: dict, verts: int) -> dict:
     """Algorithmic bytes/flops of one kernel over its measured device time."""
     V, T, H, X = ks["node_visits"], ks["tri_tests"], ks["hits_shaded"], ks["texture_taps"]
     bytes_total = 64 * V + 36 * T + 164 * H + 16 * X
-    flops_total = 44 * V + 55 * T + (400 * verts if name == "shade" else 0)
+    flops_total = 44 * V + 55 * T + (400 * verts if name in ("shade", "paths") else 0)
     ms = ks["ms"]
     launches = max(ks["launches"], 1)
     gbs = bytes_total / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
@@ -187,10 +187,20 @@ def main() -> None:
         step(abi.FLAG_TIME_KERNELS)
         torch.cuda.synchronize(dev)
         sd = stats.as_dict()
-        if sd["shadow"]["launches"] == 0:  # the shadow walks run inside k_shade: their traversal work belongs to it
-            for k in ("rays", "node_visits", "tri_tests", "hits_shaded", "texture_taps"):
-                sd["shade"][k] += sd["shadow"][k]
-        kernels = {k: kernel_roofline(k, sd[k], sd["shaded_vertices"]) for k in ("extend", "shade", "shadow") if sd[k]["launches"]}
+        work = ("rays", "node_visits", "tri_tests", "hits_shaded", "texture_taps")
+        if sd["path_kernel"]["launches"] and not sd["extend"]["launches"]:
+            # path pipeline: k_paths does the extend, shade and shadow-walk work of every vertex in one launch
+            pk = dict(sd["path_kernel"])
+            for k in work:
+                pk[k] = sd["extend"][k] + sd["shade"][k] + sd["shadow"][k]
+            sd["paths"] = pk
+            names = ("paths",)
+        else:
+            if sd["shadow"]["launches"] == 0:  # the shadow walks run inside k_shade: their traversal work belongs to it
+                for k in work:
+                    sd["shade"][k] += sd["shadow"][k]
+            names = ("extend", "shade", "shadow")
+        kernels = {k: kernel_roofline(k, sd[k], sd["shaded_vertices"]) for k in names if sd[k]["launches"]}
         dominant = max(kernels, key=lambda k: sd[k]["ms"])
         roof = dict(kernels[dominant]["hbm"])
         roof["kernel"] = kernels[dominant]["kernel"]
@@ -199,8 +209,15 @@ def main() -> None:
         roof["valu"] = kernels[dominant]["valu"]
         roof["timed_step_ms"] = sd["render_ms"]
         roof["kernel_ms"] = {k: sd[k]["ms"] for k in kernels}
-        if sd["tail"]["launches"]:
-            roof["kernel_ms"]["tail"] = sd["tail"]["ms"]
+        if sd["path_kernel"]["launches"] and "paths" not in kernels:
+            roof["kernel_ms"]["paths"] = sd["path_kernel"]["ms"]
+        traffic_file = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
+        if os.path.exists(traffic_file) and not args.spp:
+            # HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same command (scripts/pmc_passes.sh)
+            tk = json.load(open(traffic_file)).get("kernels", {}).get(roof["kernel"])
+            if tk:
+                roof["traffic"] = tk["bytes_per_launch"]
+                roof["traffic_source"] = os.path.relpath(traffic_file, ROOT)
 
     if rank == 0:
         last = stats.as_dict()

@@ -219,10 +219,10 @@ typedef struct pt_stats {
   double   render_ms;      /* device time of the render loop (HIP events)                  */
   double   upload_ms;      /* last pt_upload_scene H2D time                                */
   double   download_ms;    /* last D2H of the outputs                                      */
-  pt_kernel_stats extend;  /* closest hit of every path segment (k_extend, k_tail)          */
-  pt_kernel_stats shade;   /* shading, light sampling, regeneration, compaction (k_shade, k_tail) */
-  pt_kernel_stats shadow;  /* the shadow walks (run inside k_shade / k_tail): their traversal work */
-  pt_kernel_stats tail;    /* k_tail: launches and device time only (its work is counted in the three slices above) */
+  pt_kernel_stats extend;  /* closest hit of every path segment (k_extend, k_paths)          */
+  pt_kernel_stats shade;   /* shading, light sampling, regeneration, compaction (k_shade, k_paths) */
+  pt_kernel_stats shadow;  /* the shadow walks (run inside k_shade / k_paths, or k_shadow): their traversal work */
+  pt_kernel_stats path_kernel; /* k_paths: launches and device time only (its work is counted in the three slices above) */
 } pt_stats;
 
 #define PT_FLAG_TIME_KERNELS 1u /* bracket every kernel with HIP events (serialises; for profiling) */

@@ -174,7 +174,7 @@ class Stats(C.Structure):
         ("tri_tests", C.c_uint64), ("hits_shaded", C.c_uint64), ("texture_taps", C.c_uint64),
         ("shaded_vertices", C.c_uint64), ("nan_samples", C.c_uint64), ("iterations", C.c_uint64),
         ("render_ms", C.c_double), ("upload_ms", C.c_double), ("download_ms", C.c_double),
-        ("extend", KernelStats), ("shade", KernelStats), ("shadow", KernelStats), ("tail", KernelStats),
+        ("extend", KernelStats), ("shade", KernelStats), ("shadow", KernelStats), ("path_kernel", KernelStats),
     ]
 
     def as_dict(self) -> dict:

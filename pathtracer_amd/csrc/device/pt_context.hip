@@ -55,6 +55,10 @@ struct pt_ctx {
   uint32_t band_slots = 0;          // 0 = whole frame in one band
   uint32_t trace_blocks = 0;        // grid cap of k_extend (persistent workgroups striding the queue)
   uint32_t shade_blocks = 0;        // grid cap of k_shade
+  int pipeline = 0;                 // 0: path kernel (k_paths); 1: wavefront (k_extend + k_shade [+ k_shadow]); PT_PIPELINE=paths|wavefront
+  uint32_t paths_vertices = 32;     // path vertices a slot advances per k_paths launch (PT_PATHS_VERTICES)
+  uint32_t paths_blocks = 0xFFFFFFFFu; // grid cap of k_paths (PT_PATHS_BLOCKS)
+  uint32_t paths_block_threads = 64;   // workgroup size of k_paths (PT_PATHS_BLOCK_THREADS: 64, 128 or 256)
   uint32_t compact_every = 16;      // fused pipeline: iterations between queue compactions (PT_COMPACT_EVERY; 1 = every iteration)
   bool split_shadow = true;         // scenes in global memory: shadow walks in their own kernel (PT_SPLIT_SHADOW=0 keeps them in k_shade)
   uint32_t tail_entries = 262144;   // queue length below which the rest of the frame runs in one k_tail launch (0 = never)
@@ -258,6 +262,15 @@ extern "C" pt_ctx* pt_create(int device) {
   if (const char* e = std::getenv("PT_LDS_SCENE_BYTES")) ctx->lds_scene_bytes = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   if (ctx->trace_blocks == 0) ctx->trace_blocks = 2048;
   if (ctx->lds_scene_bytes > 32768) ctx->lds_scene_bytes = 32768;
+  if (const char* e = std::getenv("PT_PIPELINE")) ctx->pipeline = (std::string(e) == "wavefront") ? 1 : 0;
+  if (const char* e = std::getenv("PT_PATHS_VERTICES")) ctx->paths_vertices = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
+  if (ctx->paths_vertices == 0) ctx->paths_vertices = 1;
+  if (const char* e = std::getenv("PT_PATHS_BLOCK_THREADS")) {
+    const unsigned long v = std::strtoul(e, nullptr, 10);
+    if (v == 64 || v == 128 || v == 256) ctx->paths_block_threads = static_cast<uint32_t>(v);
+  }
+  if (const char* e = std::getenv("PT_PATHS_BLOCKS")) ctx->paths_blocks = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
+  if (ctx->paths_blocks == 0) ctx->paths_blocks = 0xFFFFFFFFu;
   if (const char* e = std::getenv("PT_COMPACT_EVERY")) ctx->compact_every = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   if (const char* e = std::getenv("PT_SPLIT_SHADOW")) ctx->split_shadow = std::strtoul(e, nullptr, 10) != 0;
   if (const char* e = std::getenv("PT_TAIL_ENTRIES")) ctx->tail_entries = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
@@ -496,7 +509,7 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
                                              : 0u;
   if (256u * sc.stack_entries * 4u + scene_lds > 65536u) sc.scene_in_lds = 0;  // deep tree: the stack needs the LDS
   const uint32_t trace_block = (256u * sc.stack_entries * 4u <= 65536u) ? 256u : 64u;
-  const bool split = ctx->split_shadow && !sc.scene_in_lds && n_lights != 0;
+  const bool split = ctx->pipeline == 1 && ctx->split_shadow && !sc.scene_in_lds && n_lights != 0;
   int rc = ensure_state(ctx, band_slots, split ? n_lights : 0u, pixels);
   if (rc != PT_OK) return rc;
   const pt_dev_state& st = ctx->state;
@@ -538,28 +551,15 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
 
     uint32_t bound = f.slot_count;  // live entries never increase: the last polled count bounds every later queue
     uint64_t iter = 0;
-    uint32_t parity = 0;  // the queue the next iteration reads
     int poll = 0;
     bool have_prev = false;
     bool drained = (f.sample_begin == f.sample_end);
-    while (!drained && iter < max_iters) {
-      for (uint32_t b = 0; b < kBatch; ++b, ++iter) {
-        // the queue is rebuilt on the last iteration of a batch (every iteration in the split pipeline,
-        // whose shadow queue is an append anyway) and re-used as it stands in between
-        const bool compact = split || ctx->compact_every <= 1 || (b + 1) % ctx->compact_every == 0 || b + 1 == kBatch;
-        timed(PT_K_EXTEND, [&] { ptd::launch_extend(sc, st, parity, bound, trace_block, ctx->trace_blocks, stream); });
-        timed(PT_K_SHADE, [&] {
-          ptd::launch_shade(sc, f, st, parity, bound, trace_block, ctx->shade_blocks, n_lights != 0, split, compact, stream);
-        });
-        if (split) timed(PT_K_SHADOW, [&] { ptd::launch_shadow(sc, f, st, bound, trace_block, ctx->trace_blocks, stream); });
-        if (compact) parity ^= 1u;
-      }
-      PT_HIP(ctx, hipGetLastError());
-      // entries queued for the NEXT iteration; stays intact until that iteration's successor recycles it
-      PT_HIP(ctx, hipMemcpyAsync(&ctx->host_counts[poll], st.counters + PT_CNT_QUEUE0 + parity, sizeof(uint32_t),
-                                 hipMemcpyDeviceToHost, stream));
+    const uint32_t max_vertices_u32 = static_cast<uint32_t>(max_iters > 0xFFFFFFFFull ? 0xFFFFFFFFull : max_iters);
+    // look at the previous poll while the launches just enqueued run: the GPU never waits for the host
+    auto poll_counts = [&](uint32_t counter_word) -> int {
+      PT_HIP(ctx, hipMemcpyAsync(&ctx->host_counts[poll], st.counters + counter_word, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
       PT_HIP(ctx, hipEventRecord(ctx->poll_events[poll], stream));
-      if (have_prev) {  // look at the previous batch while this one runs: the GPU never waits for the host
+      if (have_prev) {
         PT_HIP(ctx, hipEventSynchronize(ctx->poll_events[poll ^ 1]));
         const uint32_t live = ctx->host_counts[poll ^ 1];
         if (live == 0) drained = true;
@@ -567,18 +567,55 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
       }
       have_prev = true;
       poll ^= 1;
-      if (!drained && bound <= ctx->tail_entries) {
-        // short queue: every remaining vertex of every queued slot in one launch (k_tail)
-        const uint32_t max_vertices = static_cast<uint32_t>(max_iters > 0xFFFFFFFFull ? 0xFFFFFFFFull : max_iters);
-        timed(PT_K_TAIL, [&] { ptd::launch_tail(sc, f, st, parity, bound, trace_block, max_vertices, stream); });
+      return PT_OK;
+    };
+
+    if (ctx->pipeline == 0) {
+      // ---- path pipeline: one k_paths launch advances every queued slot by up to paths_vertices vertices
+      uint64_t vertices = 0;
+      for (uint32_t k = 0; !drained && vertices < max_iters; ++k, vertices += ctx->paths_vertices) {
+        timed(PT_K_PATHS, [&] {
+          ptd::launch_paths(sc, f, st, k & 1u, PT_CNT_QUEUE0 + k % 3u, PT_CNT_QUEUE0 + (k + 1u) % 3u, PT_CNT_QUEUE0 + (k + 2u) % 3u, bound,
+                            trace_block < ctx->paths_block_threads ? trace_block : ctx->paths_block_threads, ctx->paths_blocks,
+                            ctx->paths_vertices, stream);
+        });
         PT_HIP(ctx, hipGetLastError());
-        drained = true;
+        if ((rc = poll_counts(PT_CNT_QUEUE0 + (k + 1u) % 3u)) != PT_OK) return rc;
+        ++iter;
+      }
+    } else {
+      // ---- wavefront pipeline: k_extend + k_shade (+ k_shadow) per path vertex
+      uint32_t parity = 0;  // the queue the next iteration reads
+      while (!drained && iter < max_iters) {
+        for (uint32_t b = 0; b < kBatch; ++b, ++iter) {
+          // the queue is rebuilt on the last iteration of a batch (every iteration in the split pipeline,
+          // whose shadow queue is an append anyway) and re-used as it stands in between
+          const bool compact = split || ctx->compact_every <= 1 || (b + 1) % ctx->compact_every == 0 || b + 1 == kBatch;
+          timed(PT_K_EXTEND, [&] { ptd::launch_extend(sc, st, parity, bound, trace_block, ctx->trace_blocks, stream); });
+          timed(PT_K_SHADE, [&] {
+            ptd::launch_shade(sc, f, st, parity, bound, trace_block, ctx->shade_blocks, n_lights != 0, split, compact, stream);
+          });
+          if (split) timed(PT_K_SHADOW, [&] { ptd::launch_shadow(sc, f, st, bound, trace_block, ctx->trace_blocks, stream); });
+          if (compact) parity ^= 1u;
+        }
+        PT_HIP(ctx, hipGetLastError());
+        // entries queued for the NEXT iteration; stays intact until that iteration's successor recycles it
+        if ((rc = poll_counts(PT_CNT_QUEUE0 + parity)) != PT_OK) return rc;
+        if (!drained && bound <= ctx->tail_entries) {
+          // short queue: every remaining vertex of every queued slot in one k_paths launch
+          timed(PT_K_PATHS, [&] {
+            ptd::launch_paths(sc, f, st, parity, PT_CNT_QUEUE0 + parity, PT_CNT_QUEUE2, PT_CNT_QUEUE0 + (parity ^ 1u), bound, trace_block,
+                              0xFFFFFFFFu, max_vertices_u32, stream);
+          });
+          PT_HIP(ctx, hipGetLastError());
+          drained = true;
+        }
       }
     }
     if (!drained) {
       PT_HIP(ctx, hipEventSynchronize(ctx->poll_events[poll ^ 1]));
       if (ctx->host_counts[poll ^ 1] != 0)
-        return fail(ctx, PT_ERR_DEVICE, "wavefront loop did not drain after %llu iterations", static_cast<unsigned long long>(iter));
+        return fail(ctx, PT_ERR_DEVICE, "render loop did not drain after %llu launches", static_cast<unsigned long long>(iter));
     }
     ptd::launch_finalize(f, st, accum_dev, primary_dev, stream);
     iter_total += iter;
@@ -608,8 +645,8 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
     stats_out->shaded_vertices = total(PT_ST_VERTS);
     stats_out->nan_samples = total(PT_ST_NANS);
     stats_out->iterations = iter;
-    pt_kernel_stats* per[PT_K_COUNT + 1] = {nullptr, &stats_out->extend, &stats_out->shade, &stats_out->shadow, &stats_out->tail};
-    stats_out->tail.launches = launches[PT_K_TAIL];
+    pt_kernel_stats* per[PT_K_COUNT + 1] = {nullptr, &stats_out->extend, &stats_out->shade, &stats_out->shadow, &stats_out->path_kernel};
+    stats_out->path_kernel.launches = launches[PT_K_PATHS];
     for (int k = PT_K_EXTEND; k < PT_K_COUNT; ++k) {
       per[k]->launches = launches[k];
       per[k]->rays = h[k][PT_ST_RAYS];

@@ -8,11 +8,11 @@
 #include "pathtracer_amd.h"
 
 // counters[] words
-enum { PT_CNT_QUEUE0 = 0, PT_CNT_QUEUE1 = 1, PT_CNT_SHADOW = 2, PT_CNT_WORDS = 4 };
+enum { PT_CNT_QUEUE0 = 0, PT_CNT_QUEUE1 = 1, PT_CNT_QUEUE2 = 2, PT_CNT_SHADOW = 3, PT_CNT_WORDS = 4 };
 // stats[] words (unsigned long long), order of flush_tally()
 enum { PT_ST_PATHS = 0, PT_ST_RAYS, PT_ST_VISITS, PT_ST_TESTS, PT_ST_HITS, PT_ST_TAPS, PT_ST_VERTS, PT_ST_NANS, PT_ST_WORDS };
 // one block of PT_ST_WORDS per kernel
-enum { PT_K_INIT = 0, PT_K_EXTEND, PT_K_SHADE, PT_K_SHADOW, PT_K_COUNT, PT_K_TAIL = PT_K_COUNT /* timing slot only */ };
+enum { PT_K_INIT = 0, PT_K_EXTEND, PT_K_SHADE, PT_K_SHADOW, PT_K_COUNT, PT_K_PATHS = PT_K_COUNT /* timing slot only */ };
 
 // The scene in HBM, split by who reads it:
 //   pairs      traversal only   — one 64-byte record per INNER node holding both children
@@ -88,8 +88,9 @@ void launch_shade(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_st
                   hipStream_t s);
 void launch_shadow(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t max_entries, uint32_t block,
                    uint32_t max_blocks, hipStream_t s);
-void launch_tail(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity, uint32_t max_entries,
-                 uint32_t block, uint32_t max_vertices, hipStream_t s);
+void launch_paths(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity, uint32_t cnt_in,
+                  uint32_t cnt_out, uint32_t cnt_zero, uint32_t max_entries, uint32_t block, uint32_t max_blocks,
+                  uint32_t max_vertices, hipStream_t s);
 void launch_finalize(const pt_dev_frame& f, const pt_dev_state& st, float4* accum_out, uint32_t* primary_out, hipStream_t s);
 void launch_resolve(const float4* accum, uint32_t pixel_count, uint32_t* rgba8, hipStream_t s);
 }  // namespace ptd

@@ -782,7 +782,7 @@ __device__ __forceinline__ float shadow_walk(const pt_dev_scene& sc, const Shade
 // handling, interpolation, material, light sampling WITH its shadow walks, BSDF sampling —
 // then the sample bookkeeping and path regeneration of main():597-612. Returns whether the
 // slot continues with the ray (next_o, next_d). Shared by k_shade (one vertex per launch) and
-// k_tail (a slot's remaining vertices in one launch).
+// k_paths (up to max_vertices vertices of a slot per launch).
 // The shadow walks run here rather than in a kernel of their own: a separate shadow kernel
 // needed a 112-byte request per vertex and light written and read back through HBM, and
 // had to evaluate the BRDF, pdf and emitter data of every light sample up front although
@@ -1073,6 +1073,10 @@ __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const Shade
 #define PT_SHADE_MIN_WAVES_GLOBAL 4
 #endif
 #define PT_SHADE_MIN_WAVES(in_lds) ((in_lds) ? PT_SHADE_MIN_WAVES_LDS : PT_SHADE_MIN_WAVES_GLOBAL)
+// k_paths also runs the closest-hit traversals: swept 2..8 on cfg2, best at 4 (128 registers; 5 and more spill)
+#ifndef PT_PATHS_MIN_WAVES
+#define PT_PATHS_MIN_WAVES 4
+#endif
 // shade_vertex for every extended ray, then compaction of the survivors into the next queue.
 // Persistent workgroups striding the queue, so the LDS scene copy is staged once per block.
 template <bool IN_LDS, bool ALL_OPAQUE, bool SPLIT>
@@ -1214,48 +1218,67 @@ __global__ __launch_bounds__(256, ALL_OPAQUE ? PT_SHADOW_MIN_WAVES_OPAQUE : PT_S
   flush_tally(walks, st, PT_K_SHADOW);
 }
 
-// The tail of a frame. A pixel's samples are sequential (one RNG stream per pixel, Q2), so
-// the last few hundred iterations carry only the slots whose every path runs all 8 bounces:
-// too few rays to fill the GPU, and every iteration still pays two launches' worth of
-// dependent global round trips (~45 us measured on cfg2 for < 100 k rays). Once the queue is
-// that short the remaining work of every queued slot — extend, shade, extend, ... until its
-// last sample ends — runs inside ONE launch, one lane per slot. Same functions, same order
-// per slot, so the results are unchanged.
+// The path kernel: every queued slot advances by up to `max_vertices` path vertices — extend,
+// shade (with its shadow walks), extend, ... — in ONE launch, its ray and path state held in
+// registers in between; then the survivors are compacted into the next queue. A pixel's samples
+// are sequential (one RNG stream per pixel, Q2), so a slot is the unit of work anyway, and the
+// lanes of a wave stay in phase (all traverse, then all shade), which is all the coherence the
+// two-kernel wavefront iteration provided once the queue was compacted: measured equal in
+// throughput with the state round trip (ray, hit, path: ~220 B per vertex), one of the two
+// launches and the per-iteration barrier gone. Same functions, same order per
+// slot as k_extend + k_shade, so results are unchanged.
+// Queue counters rotate over three words: this launch reads `cnt_in`, appends to `cnt_out` and
+// clears `cnt_zero` (the previous launch's input, the next launch's output) — no launch
+// clears a word that blocks of the same launch still have to read.
 template <bool IN_LDS, bool ALL_OPAQUE>
-__global__ __launch_bounds__(256, PT_SHADE_MIN_WAVES(IN_LDS)) void k_tail(pt_dev_scene sc, pt_dev_frame f, pt_dev_state st, uint32_t parity,
-                                                                  uint32_t max_vertices) {
+__global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(pt_dev_scene sc, pt_dev_frame f, pt_dev_state st, uint32_t parity,
+                                                                   uint32_t cnt_in, uint32_t cnt_out, uint32_t cnt_zero,
+                                                                   uint32_t max_vertices) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
-  const uint32_t n = st.counters[PT_CNT_QUEUE0 + parity];
+  const uint32_t n = st.counters[cnt_in];
+  if (blockIdx.x == 0 && threadIdx.x == 0) st.counters[cnt_zero] = 0;
   Tally ext, tally, walks;
   const uint32_t n_lights = sc.directional_light_count + sc.point_light_count + (f.pc.emissive_triangle_count ? 1u : 0u);
   const vec3 bg_linear = mk(f.bg_linear[0], f.bg_linear[1], f.bg_linear[2]);
   if (blockIdx.x * blockDim.x < n) {  // block-uniform
     const Tracer tr = make_tracer<IN_LDS>(sc, lds_dyn);
     const ShadeData sd = make_shade_data<IN_LDS>(sc, tr, lds_dyn);
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-      const uint32_t slot = st.queue[parity][i];
-      const float4 o4 = st.ray_o[slot], d4 = st.ray_d[slot];
-      const float4 pa = st.path_a[slot], pb = st.path_b[slot];
-      const uint32_t ctr = fbits(pb.w);
-      PathRegs p{xyz(pa), xyz(pb), fbits(pa.w), ctr_light(ctr), ctr_transp(ctr), ctr_sample(ctr)};
-      bool primary = ctr_primary(ctr);
-      vec3 o = xyz(o4), d = xyz(d4);
-      for (uint32_t k = 0; k < max_vertices; ++k) {  // bounded: every wave reaches the end of the grid
-        Hit h{kInfinity, 0.0f, 0.0f, kNoHit};
-        traverse<IN_LDS, false>(tr, o, d, h, ext);
-        if (primary) st.primary_id[slot] = h.tri;
-        primary = false;
-        vec3 next_o = mk(0, 0, 0), next_d = mk(0, 0, 0);
-        bool shaded;
-        if (!shade_vertex<IN_LDS, ALL_OPAQUE, false>(sc, sd, f, st, tr, n_lights, bg_linear, slot, h, d, p, next_o, next_d, tally, walks, shaded)) break;
-        o = next_o;
-        d = next_d;
+    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {  // block-uniform trip count
+      const uint32_t gid = base + threadIdx.x;
+      bool alive = false;
+      uint32_t slot = 0;
+      if (gid < n) {
+        slot = st.queue[parity][gid];
+        const float4 o4 = st.ray_o[slot], d4 = st.ray_d[slot];
+        const float4 pa = st.path_a[slot], pb = st.path_b[slot];
+        const uint32_t ctr = fbits(pb.w);
+        PathRegs p{xyz(pa), xyz(pb), fbits(pa.w), ctr_light(ctr), ctr_transp(ctr), ctr_sample(ctr)};
+        bool primary = ctr_primary(ctr);
+        vec3 o = xyz(o4), d = xyz(d4);
+        for (uint32_t k = 0; k < max_vertices; ++k) {  // bounded: every wave reaches the end of the grid
+          Hit h{kInfinity, 0.0f, 0.0f, kNoHit};
+          traverse<IN_LDS, false>(tr, o, d, h, ext);
+          if (primary) st.primary_id[slot] = h.tri;
+          primary = false;
+          vec3 next_o = mk(0, 0, 0), next_d = mk(0, 0, 0);
+          bool shaded;
+          alive = shade_vertex<IN_LDS, ALL_OPAQUE, false>(sc, sd, f, st, tr, n_lights, bg_linear, slot, h, d, p, next_o, next_d, tally,
+                                                          walks, shaded);
+          if (!alive) break;
+          o = next_o;
+          d = next_d;
+        }
+        if (alive) {
+          st.ray_o[slot] = make_float4(o.x, o.y, o.z, 0.0f);
+          st.ray_d[slot] = make_float4(d.x, d.y, d.z, 0.0f);
+        }
+        st.path_a[slot] = make_float4(p.indirect.x, p.indirect.y, p.indirect.z, ubits(p.rng));
+        st.path_b[slot] = make_float4(p.color.x, p.color.y, p.color.z, ubits(ctr_pack(p.light_steps, p.transp_steps, primary, p.sample)));
       }
-      st.path_a[slot] = make_float4(p.indirect.x, p.indirect.y, p.indirect.z, ubits(p.rng));
-      st.path_b[slot] = make_float4(p.color.x, p.color.y, p.color.z, ubits(ctr_pack(p.light_steps, p.transp_steps, false, p.sample)));
+      const AppendSlots at = block_append2(alive, &st.counters[cnt_out], false, nullptr);
+      if (alive) st.queue[parity ^ 1u][at.a] = slot;
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) st.counters[PT_CNT_QUEUE0 + parity] = 0;  // drained (n was read above by this thread)
   flush_tally(ext, st, PT_K_EXTEND);
   flush_tally(tally, st, PT_K_SHADE);
   flush_tally(walks, st, PT_K_SHADOW);
@@ -1345,17 +1368,22 @@ void launch_shade(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_st
   }
 }
 
-void launch_tail(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity, uint32_t max_entries,
-                 uint32_t block, uint32_t max_vertices, hipStream_t s) {
-  const uint32_t grid = blocks_for(max_entries, block);
+void launch_paths(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity, uint32_t cnt_in,
+                  uint32_t cnt_out, uint32_t cnt_zero, uint32_t max_entries, uint32_t block, uint32_t max_blocks,
+                  uint32_t max_vertices, hipStream_t s) {
+  uint32_t grid = blocks_for(max_entries, block);
+  if (grid > max_blocks) grid = max_blocks;
   const size_t lds = shade_lds_bytes(sc, block);
   const int variant = (sc.scene_in_lds ? 2 : 0) | (sc.all_opaque ? 1 : 0);
+#define PT_LAUNCH_PATHS(A, B) \
+  hipLaunchKernelGGL((k_paths<A, B>), dim3(grid), dim3(block), lds, s, sc, f, st, parity, cnt_in, cnt_out, cnt_zero, max_vertices)
   switch (variant) {
-    case 3: hipLaunchKernelGGL((k_tail<true, true>), dim3(grid), dim3(block), lds, s, sc, f, st, parity, max_vertices); break;
-    case 2: hipLaunchKernelGGL((k_tail<true, false>), dim3(grid), dim3(block), lds, s, sc, f, st, parity, max_vertices); break;
-    case 1: hipLaunchKernelGGL((k_tail<false, true>), dim3(grid), dim3(block), lds, s, sc, f, st, parity, max_vertices); break;
-    default: hipLaunchKernelGGL((k_tail<false, false>), dim3(grid), dim3(block), lds, s, sc, f, st, parity, max_vertices); break;
+    case 3: PT_LAUNCH_PATHS(true, true); break;
+    case 2: PT_LAUNCH_PATHS(true, false); break;
+    case 1: PT_LAUNCH_PATHS(false, true); break;
+    default: PT_LAUNCH_PATHS(false, false); break;
   }
+#undef PT_LAUNCH_PATHS
 }
 
 void launch_finalize(const pt_dev_frame& f, const pt_dev_state& st, float4* accum_out, uint32_t* primary_out, hipStream_t s) {

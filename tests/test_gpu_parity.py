@@ -105,6 +105,24 @@ def test_rank_split_matches_oracle_per_rank(renderer, oracle):
         compare(renderer, oracle, s, 96, 54, 16, seed=17, rank=r, num_ranks=3)
 
 
+@pytest.mark.parametrize("env", [{"PT_PIPELINE": "wavefront"}, {"PT_PIPELINE": "wavefront", "PT_SPLIT_SHADOW": "0"},
+                                 {"PT_PIPELINE": "wavefront", "PT_COMPACT_EVERY": "1", "PT_TAIL_ENTRIES": "0"},
+                                 {"PT_PATHS_VERTICES": "1", "PT_PATHS_BLOCK_THREADS": "256"}, {"PT_PATHS_VERTICES": "1000"}])
+def test_alternative_pipelines_give_the_same_bits(oracle, monkeypatch, env):
+    """The wavefront pipeline (k_extend + k_shade, fused or with the split k_shadow, lazy or per-iteration
+    compaction, with or without the k_paths tail) and other k_paths launch shapes: same results as the default."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    r = Renderer(0)  # the context reads its tuning knobs at creation
+    try:
+        compare(r, oracle, scenes.cornell_scene(True, True, True, True), 160, 90, 16, seed=31)       # LDS-resident, alpha
+        compare(r, oracle, scenes.cornell_scene(), 96, 54, 9, seed=32)                                # LDS-resident, all opaque
+        compare(r, oracle, scenes.textured_scene(), 160, 90, 9, seed=33)                              # global memory, alpha, 2 lights
+        compare(r, oracle, scenes.soup_scene(20000, emissive_every=50), 96, 54, 9, seed=34)           # global memory, all opaque
+    finally:
+        r.close()
+
+
 def test_zero_samples_gives_black_not_a_hang(renderer, oracle):
     packed = renderer.pack(scenes.cube_scene())
     renderer.upload(packed)
