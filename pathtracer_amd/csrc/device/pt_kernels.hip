@@ -125,9 +125,20 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
   return v;
 }
 
+#ifdef PT_EXP_NO_TALLY  // experiment: what the work counters cost
+struct NoCount {
+  __device__ NoCount& operator++() { return *this; }
+  __device__ NoCount& operator+=(uint32_t) { return *this; }
+  __device__ operator uint32_t() const { return 0u; }
+};
+struct Tally {
+  NoCount rays, visits, tests, hits, taps, verts, paths, nans;
+};
+#else
 struct Tally {  // per-thread work counters, flushed once per kernel
   uint32_t rays = 0, visits = 0, tests = 0, hits = 0, taps = 0, verts = 0, paths = 0, nans = 0;
 };
+#endif
 
 // Work counters without atomics: wave reduction, LDS across the block's waves, then lanes
 // 0..7 of the block add the eight sums into the block's OWN row of the partial table
@@ -1077,6 +1088,9 @@ __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const Shade
 #ifndef PT_PATHS_MIN_WAVES
 #define PT_PATHS_MIN_WAVES 4
 #endif
+#ifndef PT_PATHS_MIN_WAVES_GLOBAL
+#define PT_PATHS_MIN_WAVES_GLOBAL 5  // scenes read from global memory: swept 3..6 on cfg3/cfg4-class scenes, best at 5
+#endif
 // shade_vertex for every extended ray, then compaction of the survivors into the next queue.
 // Persistent workgroups striding the queue, so the LDS scene copy is staged once per block.
 template <bool IN_LDS, bool ALL_OPAQUE, bool SPLIT>
@@ -1231,7 +1245,7 @@ __global__ __launch_bounds__(256, ALL_OPAQUE ? PT_SHADOW_MIN_WAVES_OPAQUE : PT_S
 // clears `cnt_zero` (the previous launch's input, the next launch's output) — no launch
 // clears a word that blocks of the same launch still have to read.
 template <bool IN_LDS, bool ALL_OPAQUE>
-__global__ __launch_bounds__(256, PT_PATHS_MIN_WAVES) void k_paths(pt_dev_scene sc, pt_dev_frame f, pt_dev_state st, uint32_t parity,
+__global__ __launch_bounds__(256, IN_LDS ? PT_PATHS_MIN_WAVES : PT_PATHS_MIN_WAVES_GLOBAL) void k_paths(pt_dev_scene sc, pt_dev_frame f, pt_dev_state st, uint32_t parity,
                                                                    uint32_t cnt_in, uint32_t cnt_out, uint32_t cnt_zero,
                                                                    uint32_t max_vertices) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
