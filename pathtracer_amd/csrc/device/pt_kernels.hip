@@ -117,6 +117,10 @@ __device__ __forceinline__ AppendSlots block_append2(bool pred_a, uint32_t* coun
     off_a += wave_count[0][i];
     off_b += wave_count[1][i];
   }
+  // A workgroup that strides the queue calls this once per trip: no wave may write its next
+  // trip's count while a slower wave still sums this trip's (a wave with nothing to do on the
+  // last, partial trip gets there at once; without this barrier 1080p frames lost ~1e-4 of their slots).
+  __syncthreads();
   return AppendSlots{off_a + mbcnt(mask_a), off_b + mbcnt(mask_b)};
 }
 

@@ -142,6 +142,51 @@ def test_render_before_upload_fails_loudly():
         r.close()
 
 
+def test_cfg2_full_size_properties(renderer, oracle, monkeypatch):
+    """BASELINE configs[1] at its full size (1920x1080, sample_count 128 -> 121 strata): size-independent
+    properties on the whole frame, a band of rows against the oracle at the full sample count, and the same
+    frame from the wavefront pipeline."""
+    import hashlib
+    packed = renderer.pack(scenes.cornell_scene())
+    renderer.upload(packed)
+    rp = packed.render_params(renderer.lib, 1920, 1080, 128, seed=0x5EED0000)
+    rgba, accum, ids, st = renderer.render_params(rp)
+    assert st["paths"] == 1920 * 1080 * 121
+    assert (accum[..., 3] <= 121).all() and int((121 - accum[..., 3]).sum()) == st["nan_samples"]
+    assert st["rays"] >= st["paths"] and st["shaded_vertices"] <= 8 * st["paths"] + 4 * st["paths"]
+    assert np.isfinite(accum).all() and (accum[..., :3] >= 0).all() and (accum[..., :3] <= 10.0 * 121).all()  # clamp 10 per sample
+    assert (rgba[..., 3] == 255).all()
+    o_rgba, o_accum, o_ids, _ = oracle_lib.render(oracle, packed, rp, threads=16, rows=(536, 548))
+    assert (ids[536:548] == o_ids[536:548]).all()
+    assert (accum[536:548].view(np.uint32) == o_accum[536:548].view(np.uint32)).all()
+    assert (rgba[536:548] == o_rgba[536:548]).all()
+    digest = hashlib.sha256(accum.tobytes() + ids.tobytes()).hexdigest()
+    rgba2, accum2, ids2, st2 = renderer.render_params(rp)  # idempotent
+    assert hashlib.sha256(accum2.tobytes() + ids2.tobytes()).hexdigest() == digest
+    # the wavefront pipeline at full size: queue striding (more entries than the shade grid), compaction on
+    # every iteration (the shape that once lost slots to a race in the block-level append) and the default
+    for env in ({"PT_PIPELINE": "wavefront", "PT_COMPACT_EVERY": "1", "PT_TAIL_ENTRIES": "0"}, {"PT_PIPELINE": "wavefront"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        r2 = Renderer(0)
+        try:
+            r2.upload(packed)
+            _, accum3, ids3, st3 = r2.render_params(rp)
+        finally:
+            r2.close()
+        for k in env:
+            monkeypatch.delenv(k)
+        for k in COUNTERS:
+            assert st[k] == st3[k], (env, k)
+        assert hashlib.sha256(accum3.tobytes() + ids3.tobytes()).hexdigest() == digest, env
+
+
+def test_4k_frame_fits_and_matches_a_band(renderer, oracle):
+    # BASELINE configs[4] resolution (3840x2160) at 4 spp: the state of 8.3 M slots, a band against the oracle
+    st = compare(renderer, oracle, scenes.cornell_scene(), 3840, 2160, 4, seed=19, rows=(1076, 1084))
+    assert st["paths"] == 3840 * 2160 * 4
+
+
 def test_cornell_1080p_band_against_oracle(renderer, oracle):
     # BASELINE configs[1] resolution; full image on the GPU at 9 spp, a 24-row band on the oracle
     compare(renderer, oracle, scenes.cornell_scene(), 1920, 1080, 9, seed=18, rows=(528, 552))
