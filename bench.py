@@ -39,6 +39,8 @@ WORKLOADS = {
     "rocks1080": ("rocks_scene", {"n_tris": 5_000_000}, 1920, 1080, 512,
                   "cfg4: generated ~5M-triangle rock clusters (deep BVH), 1920x1080, 512 spp (484 effective)"),
 }
+WORKLOADS["cornell4k"] = ("cornell_scene", {}, 3840, 2160, 4096,
+                          "cfg5: Cornell box + area light, 3840x2160, 4096 spp (64x64 strata), one GPU's share when N > 1 is the full frame (weak scaling)")
 BG = {"atrium1080": (0.5, 0.7, 1.0), "rocks1080": (0.5, 0.7, 1.0), "soup1080": (0.5, 0.7, 1.0)}  # sky; others: README default
 
 
@@ -69,11 +71,14 @@ def cpu_baseline(packed, rp, seconds_hint: float = 15.0) -> dict:
     h = rp.pc.resolution_y
     # warm up (library load, thread start), calibrate on 4 rows, then size the band for ~seconds_hint
     mid = h // 2
+    t0 = time.perf_counter()
     oracle_lib.render(lib, packed, rp, threads=cores, rows=(mid, min(mid + 1, h)), want_ids=False)
-    cal = min(4, h)
+    first = time.perf_counter() - t0
+    cal = 1 if first > 2.0 else min(4, h)  # heavy workloads (hundreds of spp on millions of triangles): one row is sample enough
     t0 = time.perf_counter()
     oracle_lib.render(lib, packed, rp, threads=cores, rows=(mid, min(mid + cal, h)), want_ids=False)
     dt = max(time.perf_counter() - t0, 1e-6)
+    progress(f"oracle: {cal} row(s) in {dt:.1f} s")
     rows = int(max(cal, min(h, cal * seconds_hint / dt)))
     y0 = max(0, mid - rows // 2)
     y1 = min(h, y0 + rows)
@@ -85,6 +90,14 @@ def cpu_baseline(packed, rp, seconds_hint: float = 15.0) -> dict:
         "kind": "port", "seconds": dt,
         "sample": f"rows {y0}..{y1} of {h} of the same frame ({st['paths']} paths, {st['rays']} rays), oracle/pt_oracle.c, {cores} threads",
     }
+
+
+T_START = time.perf_counter()
+
+
+def progress(msg: str) -> None:
+    """One line on stderr per phase: long workloads (5 M triangles) must not look hung."""
+    print(f"[bench +{time.perf_counter() - T_START:6.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
 def main() -> None:
@@ -124,12 +137,16 @@ def main() -> None:
     factory, kwargs, width, height, spp, desc = WORKLOADS[args.workload]
     if args.spp:
         spp = args.spp
+    progress(f"generating {args.workload}")
     scene = getattr(scenes, factory)(**kwargs)
+    progress(f"{len(scene.triangles)} triangles; building the BVH")
     r = Renderer(local_rank)
     t0 = time.perf_counter()
     packed = r.pack(scene)
     build_s = time.perf_counter() - t0
+    progress(f"{len(packed.nodes)} nodes, depth {packed.bvh_max_depth}; uploading")
     r.upload(packed)
+    progress("rendering")
     from pathtracer_amd.distributed import rank_seed
     seed = rank_seed(0x5EED0000, rank)  # "replicate" split: one decorrelated stream family per rank
     rp = packed.render_params(r.lib, width, height, spp, BG.get(args.workload, (0.239, 0.239, 0.239)), seed)
@@ -171,6 +188,7 @@ def main() -> None:
         render_ms += stats.render_ms
     fence()
     elapsed = time.perf_counter() - t0
+    progress(f"{args.steps} timed steps in {elapsed:.2f} s")
 
     tot = torch.tensor([elapsed, float(rays), float(paths)], dtype=torch.float64, device=dev)
     if world > 1:
@@ -244,6 +262,7 @@ def main() -> None:
             out["roofline"] = roof
             out["kernels"] = kernels
         if not args.no_cpu_baseline and world == 1:
+            progress("timing the CPU oracle on a band of rows")
             out["cpu_baseline"] = cpu_baseline(packed, rp)
         print(json.dumps(out))
     if world > 1:

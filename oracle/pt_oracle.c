@@ -989,10 +989,14 @@ static void* worker_main(void* p) {
   c.any_hit_shadows = w->any_hit_shadows;
   c.cull_behind = w->cull_behind;
   c.stack = (uint32_t*)malloc(sizeof(uint32_t) * (w->sc->bvh_max_depth + 64)); /* main.comp:263-265 */
+  /* work unit: 32 consecutive pixels of a row, so that even a one-row band keeps every thread busy */
+  const uint32_t chunks_per_row = (c.pc->resolution_x + 31u) / 32u;
+  const uint32_t chunk_end = (w->y_end > w->y_begin ? w->y_end - w->y_begin : 0u) * chunks_per_row;
   for (;;) {
-    uint32_t y = __sync_fetch_and_add(w->next_row, 1u);
-    if (y >= w->y_end) break;
-    for (uint32_t x = 0; x < c.pc->resolution_x; ++x)
+    uint32_t chunk = __sync_fetch_and_add(w->next_row, 1u);
+    if (chunk >= chunk_end) break;
+    const uint32_t y = w->y_begin + chunk / chunks_per_row, x0 = (chunk % chunks_per_row) * 32u;
+    for (uint32_t x = x0; x < x0 + 32u && x < c.pc->resolution_x; ++x)
       shade_pixel(&c, x, y, w->rp->rank, w->rp->num_ranks, w->rgba8, w->accum, w->primary_id);
   }
   free(c.stack);
@@ -1032,7 +1036,7 @@ int orc_render_ex(const pt_scene_desc* scene, const pt_render_params* params, ui
   if (y_end > params->pc.resolution_y) y_end = params->pc.resolution_y;
   if (num_threads < 1) num_threads = 1;
   if (num_threads > 256) num_threads = 256;
-  volatile uint32_t next_row = y_begin;
+  volatile uint32_t next_row = 0; /* next 32-pixel chunk of the band */
   const int any_hit = (flags & ORC_FLAG_ANYHIT_OPAQUE_SHADOW) && orc_scene_all_opaque(scene);
   pthread_t th[256];
   worker_arg args[256];
