@@ -1251,17 +1251,21 @@ __global__ __launch_bounds__(256, ALL_OPAQUE ? PT_SHADOW_MIN_WAVES_OPAQUE : PT_S
 template <bool IN_LDS, bool ALL_OPAQUE>
 __global__ __launch_bounds__(256, IN_LDS ? PT_PATHS_MIN_WAVES : PT_PATHS_MIN_WAVES_GLOBAL) void k_paths(pt_dev_scene sc, pt_dev_frame f, pt_dev_state st, uint32_t parity,
                                                                    uint32_t cnt_in, uint32_t cnt_out, uint32_t cnt_zero,
-                                                                   uint32_t max_vertices) {
+                                                                   uint32_t max_vertices, uint32_t xcd_remap) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
   const uint32_t n = st.counters[cnt_in];
   if (blockIdx.x == 0 && threadIdx.x == 0) st.counters[cnt_zero] = 0;
   Tally ext, tally, walks;
   const uint32_t n_lights = sc.directional_light_count + sc.point_light_count + (f.pc.emissive_triangle_count ? 1u : 0u);
   const vec3 bg_linear = mk(f.bg_linear[0], f.bg_linear[1], f.bg_linear[2]);
-  if (blockIdx.x * blockDim.x < n) {  // block-uniform
+  // Workgroups go to the 8 XCDs round-robin (each with its own 4 MiB L2). With `xcd_remap` (the grid is then a
+  // multiple of 8) XCD x works on the x-th contiguous eighth of the queue, so neighbouring tiles of the image
+  // share an L2 instead of being dealt out over all eight.
+  const uint32_t vblock = xcd_remap ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  if (vblock * blockDim.x < n) {  // block-uniform
     const Tracer tr = make_tracer<IN_LDS>(sc, lds_dyn);
     const ShadeData sd = make_shade_data<IN_LDS>(sc, tr, lds_dyn);
-    for (uint32_t base = blockIdx.x * blockDim.x; base < n; base += gridDim.x * blockDim.x) {  // block-uniform trip count
+    for (uint32_t base = vblock * blockDim.x; base < n; base += gridDim.x * blockDim.x) {  // block-uniform trip count
       const uint32_t gid = base + threadIdx.x;
       bool alive = false;
       uint32_t slot = 0;
@@ -1388,13 +1392,15 @@ void launch_shade(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_st
 
 void launch_paths(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity, uint32_t cnt_in,
                   uint32_t cnt_out, uint32_t cnt_zero, uint32_t max_entries, uint32_t block, uint32_t max_blocks,
-                  uint32_t max_vertices, hipStream_t s) {
+                  uint32_t max_vertices, bool xcd_remap, hipStream_t s) {
   uint32_t grid = blocks_for(max_entries, block);
   if (grid > max_blocks) grid = max_blocks;
+  if (xcd_remap) grid = (grid + 7u) & ~7u;
+  const uint32_t remap = xcd_remap ? 1u : 0u;
   const size_t lds = shade_lds_bytes(sc, block);
   const int variant = (sc.scene_in_lds ? 2 : 0) | (sc.all_opaque ? 1 : 0);
 #define PT_LAUNCH_PATHS(A, B) \
-  hipLaunchKernelGGL((k_paths<A, B>), dim3(grid), dim3(block), lds, s, sc, f, st, parity, cnt_in, cnt_out, cnt_zero, max_vertices)
+  hipLaunchKernelGGL((k_paths<A, B>), dim3(grid), dim3(block), lds, s, sc, f, st, parity, cnt_in, cnt_out, cnt_zero, max_vertices, remap)
   switch (variant) {
     case 3: PT_LAUNCH_PATHS(true, true); break;
     case 2: PT_LAUNCH_PATHS(true, false); break;
