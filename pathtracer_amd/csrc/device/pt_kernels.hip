@@ -1093,7 +1093,7 @@ __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const Shade
 #define PT_PATHS_MIN_WAVES 4
 #endif
 #ifndef PT_PATHS_MIN_WAVES_GLOBAL
-#define PT_PATHS_MIN_WAVES_GLOBAL 5  // scenes read from global memory: swept 3..6 on cfg3/cfg4-class scenes, best at 5
+#define PT_PATHS_MIN_WAVES_GLOBAL 5  // scenes beyond an XCD's L2: swept 3..6 on cfg3/cfg4-class scenes, best at 5
 #endif
 // shade_vertex for every extended ray, then compaction of the survivors into the next queue.
 // Persistent workgroups striding the queue, so the LDS scene copy is staged once per block.
@@ -1248,8 +1248,8 @@ __global__ __launch_bounds__(256, ALL_OPAQUE ? PT_SHADOW_MIN_WAVES_OPAQUE : PT_S
 // Queue counters rotate over three words: this launch reads `cnt_in`, appends to `cnt_out` and
 // clears `cnt_zero` (the previous launch's input, the next launch's output) — no launch
 // clears a word that blocks of the same launch still have to read.
-template <bool IN_LDS, bool ALL_OPAQUE>
-__global__ __launch_bounds__(256, IN_LDS ? PT_PATHS_MIN_WAVES : PT_PATHS_MIN_WAVES_GLOBAL) void k_paths(pt_dev_scene sc, pt_dev_frame f, pt_dev_state st, uint32_t parity,
+template <bool IN_LDS, bool ALL_OPAQUE, int MIN_WAVES>
+__global__ __launch_bounds__(256, MIN_WAVES) void k_paths(pt_dev_scene sc, pt_dev_frame f, pt_dev_state st, uint32_t parity,
                                                                    uint32_t cnt_in, uint32_t cnt_out, uint32_t cnt_zero,
                                                                    uint32_t max_vertices, uint32_t xcd_remap) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
@@ -1399,13 +1399,22 @@ void launch_paths(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_st
   const uint32_t remap = xcd_remap ? 1u : 0u;
   const size_t lds = shade_lds_bytes(sc, block);
   const int variant = (sc.scene_in_lds ? 2 : 0) | (sc.all_opaque ? 1 : 0);
-#define PT_LAUNCH_PATHS(A, B) \
-  hipLaunchKernelGGL((k_paths<A, B>), dim3(grid), dim3(block), lds, s, sc, f, st, parity, cnt_in, cnt_out, cnt_zero, max_vertices, remap)
+  // occupancy bound by scene class (swept): 4 waves/SIMD while the scene sits in LDS or in an XCD's L2
+  // (VALU bound: spills cost more than a 5th wave hides), 5 once its fetches go to the Infinity Cache / HBM
+  const bool big = !sc.scene_in_lds && 64ull * sc.pair_count + 48ull * sc.triangle_count > (4ull << 20);
+#define PT_LAUNCH_PATHS(A, B, W) \
+  hipLaunchKernelGGL((k_paths<A, B, W>), dim3(grid), dim3(block), lds, s, sc, f, st, parity, cnt_in, cnt_out, cnt_zero, max_vertices, remap)
   switch (variant) {
-    case 3: PT_LAUNCH_PATHS(true, true); break;
-    case 2: PT_LAUNCH_PATHS(true, false); break;
-    case 1: PT_LAUNCH_PATHS(false, true); break;
-    default: PT_LAUNCH_PATHS(false, false); break;
+    case 3: PT_LAUNCH_PATHS(true, true, PT_PATHS_MIN_WAVES); break;
+    case 2: PT_LAUNCH_PATHS(true, false, PT_PATHS_MIN_WAVES); break;
+    case 1:
+      if (big) PT_LAUNCH_PATHS(false, true, PT_PATHS_MIN_WAVES_GLOBAL);
+      else PT_LAUNCH_PATHS(false, true, PT_PATHS_MIN_WAVES);
+      break;
+    default:
+      if (big) PT_LAUNCH_PATHS(false, false, PT_PATHS_MIN_WAVES_GLOBAL);
+      else PT_LAUNCH_PATHS(false, false, PT_PATHS_MIN_WAVES);
+      break;
   }
 #undef PT_LAUNCH_PATHS
 }
