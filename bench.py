@@ -229,6 +229,13 @@ def main() -> None:
         roof["kernel_ms"] = {k: sd[k]["ms"] for k in kernels}
         if sd["path_kernel"]["launches"] and "paths" not in kernels:
             roof["kernel_ms"]["paths"] = sd["path_kernel"]["ms"]
+        scene_bytes = 64 * (len(packed.nodes) // 2) + 48 * int(scene.triangles.shape[0])
+        if scene_bytes > 16384:
+            # scenes read from global memory: the measured ceiling of dependent random 64-byte gathers on this GPU
+            # (scripts/micro/gather64.hip: 11.1 TB/s within one XCD's L2, 4.4 TB/s at 32 MiB, 3.55 TB/s from 128 MiB up)
+            ceiling = 11100.0 if scene_bytes <= (4 << 20) else (4400.0 if scene_bytes <= (48 << 20) else 3550.0)
+            roof["random_gather_ceiling_gbs"] = ceiling
+            roof["frac_of_gather_ceiling"] = roof["achieved"] / ceiling
         traffic_file = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
         if os.path.exists(traffic_file) and not args.spp:
             # HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same command (scripts/pmc_passes.sh)
