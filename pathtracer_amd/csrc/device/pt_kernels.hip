@@ -1,21 +1,22 @@
-// Wavefront path-tracing kernels for gfx950 (wave64): the device half of the hot path,
-// i.e. the work of src/renderer/shaders/main.comp re-organised from "one invocation owns
-// a pixel for all its samples" into queues of path segments:
+// Path-tracing kernels for gfx950 (wave64): the device half of the hot path, i.e. the work of
+// src/renderer/shaders/main.comp re-organised from "one invocation owns a pixel for all its
+// samples, one dispatch" into queues of pixel slots that are re-compacted as pixels finish:
 //
 //   k_init     main():588-605 for the first sample of every pixel slot
-//   k_extend   ray_scene_intersect (main.comp:263-304) for every queued ray
-//   k_shade    trace() body (main.comp:517-577) for every extended ray: miss handling,
-//              interpolation, material, light sampling set-up, BSDF sampling, path
-//              regeneration (main():597-612) and queue compaction
-//   k_shadow   ray_scene_intersect_with_transparency (main.comp:306-332) for the vertex's
-//              light samples and the direct-lighting accumulate (main.comp:536-552)
+//   k_paths    (default pipeline) up to 32 path vertices of every queued slot per launch:
+//              ray_scene_intersect (main.comp:263-304), then the trace() body (:517-577) with its
+//              light sampling and shadow walks (:306-332, 409-501), BSDF sampling, NaN filter and
+//              regeneration (main():597-612); survivors compacted into the next queue
+//   k_extend / k_shade / k_shadow   (wavefront pipeline, PT_PIPELINE=wavefront) the same work as one
+//              traversal launch + one shading launch per vertex, shadow walks fused into k_shade
+//              (LDS-resident scenes) or deferred to k_shadow (scenes in global memory)
 //   k_finalize slot order -> pixel order, float4 accumulator + primary-hit ids
 //   k_resolve  main():616-619
 //
 // A pixel owns ONE RNG stream consumed sequentially across all its samples,
 // so a pixel slot carries one path at a time and regenerates the next sample as soon as
-// the current one ends; the queues hold slot indices and are re-compacted every
-// iteration with ballot + mbcnt (one atomic per wave).
+// the current one ends; the queues hold slot indices and are compacted with ballot + mbcnt
+// and one atomic per workgroup.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -82,19 +83,6 @@ struct AppendSlots {
   uint32_t a, b;
 };
 __device__ __forceinline__ AppendSlots block_append2(bool pred_a, uint32_t* counter_a, bool pred_b, uint32_t* counter_b) {
-#ifdef PT_EXP_WAVE_APPEND  // experiment: one atomic per wave, no barrier
-  {
-    const uint64_t ma = __ballot(pred_a), mb = __ballot(pred_b);
-    uint32_t base_a = 0, base_b = 0;
-    if (lane_id() == 0) {
-      if (ma && counter_a) base_a = atomicAdd(counter_a, static_cast<uint32_t>(__popcll(ma)));
-      if (mb && counter_b) base_b = atomicAdd(counter_b, static_cast<uint32_t>(__popcll(mb)));
-    }
-    base_a = __builtin_amdgcn_readfirstlane(base_a);
-    base_b = __builtin_amdgcn_readfirstlane(base_b);
-    return AppendSlots{base_a + mbcnt(ma), base_b + mbcnt(mb)};
-  }
-#endif
   __shared__ uint32_t wave_count[2][4];
   __shared__ uint32_t block_base[2];
   const uint64_t mask_a = __ballot(pred_a), mask_b = __ballot(pred_b);
@@ -129,20 +117,9 @@ __device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
   return v;
 }
 
-#ifdef PT_EXP_NO_TALLY  // experiment: what the work counters cost
-struct NoCount {
-  __device__ NoCount& operator++() { return *this; }
-  __device__ NoCount& operator+=(uint32_t) { return *this; }
-  __device__ operator uint32_t() const { return 0u; }
-};
-struct Tally {
-  NoCount rays, visits, tests, hits, taps, verts, paths, nans;
-};
-#else
 struct Tally {  // per-thread work counters, flushed once per kernel
   uint32_t rays = 0, visits = 0, tests = 0, hits = 0, taps = 0, verts = 0, paths = 0, nans = 0;
 };
-#endif
 
 // Work counters without atomics: wave reduction, LDS across the block's waves, then lanes
 // 0..7 of the block add the eight sums into the block's OWN row of the partial table
@@ -764,9 +741,6 @@ template <bool IN_LDS, bool ALL_OPAQUE>
 __device__ __forceinline__ float shadow_walk(const pt_dev_scene& sc, const ShadeData& sd, const Tracer& tr, vec3 origin, vec3 dir,
                                              Hit& h, Tally& tally) {
   float transparency = 1.0f;
-#ifdef PT_EXP_NO_SHADOW  // timing experiment only: skip the walk (wrong images)
-  return transparency;
-#endif
   if (ALL_OPAQUE) {  // every closest hit has alpha == 1 and returns 0 (main.comp:325): any hit decides
     h.t = kInfinity;
     h.tri = kNoHit;
