@@ -59,8 +59,7 @@ struct pt_ctx {
   uint32_t paths_vertices = 32;     // path vertices a slot advances per k_paths launch (PT_PATHS_VERTICES)
   uint32_t paths_blocks = 0xFFFFFFFFu; // grid cap of k_paths (PT_PATHS_BLOCKS)
   uint32_t paths_block_threads = 64;   // workgroup size of k_paths (PT_PATHS_BLOCK_THREADS: 64, 128 or 256)
-  bool xcd_remap = false;           // k_paths: contiguous eighth of the queue per XCD (PT_XCD_REMAP=1). Measured 8-18 % SLOWER on the
-                                    // global-memory scenes: workgroups are dealt to XCDs round-robin, so image regions of unequal cost unbalance them
+  uint32_t xcd_chunk = 0;           // k_paths: deal the queue to the XCDs in chunks of this many workgroups (PT_XCD_CHUNK; 0 = plain round-robin)
   uint32_t compact_every = 16;      // fused pipeline: iterations between queue compactions (PT_COMPACT_EVERY; 1 = every iteration)
   bool split_shadow = true;         // scenes in global memory: shadow walks in their own kernel (PT_SPLIT_SHADOW=0 keeps them in k_shade)
   uint32_t tail_entries = 262144;   // queue length below which the rest of the frame runs in one k_tail launch (0 = never)
@@ -205,7 +204,7 @@ int ensure_state(pt_ctx* ctx, uint32_t slots, uint32_t lights, uint32_t pixels) 
   ALLOC(st.req, 4 * static_cast<size_t>(lights) * slots);
   ALLOC(st.queue_shadow, lights ? slots : 0);
   ALLOC(st.counters, PT_CNT_WORDS);
-  st.stat_rows = slots / 64 + 9;  // >= the largest grid (64-thread blocks, rounded up to a multiple of 8)
+  st.stat_rows = slots / 64 * 2 + 16;  // >= the largest grid (64-thread blocks, rounded up to a multiple of 8)
   ALLOC(st.stats, static_cast<size_t>(PT_K_COUNT) * st.stat_rows * PT_ST_WORDS);
   ALLOC(ctx->accum_out, pixels);
   ALLOC(ctx->primary_out, pixels);
@@ -273,7 +272,7 @@ extern "C" pt_ctx* pt_create(int device) {
   }
   if (const char* e = std::getenv("PT_PATHS_BLOCKS")) ctx->paths_blocks = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   if (ctx->paths_blocks == 0) ctx->paths_blocks = 0xFFFFFFFFu;
-  if (const char* e = std::getenv("PT_XCD_REMAP")) ctx->xcd_remap = std::strtoul(e, nullptr, 10) != 0;
+  if (const char* e = std::getenv("PT_XCD_CHUNK")) ctx->xcd_chunk = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   if (const char* e = std::getenv("PT_COMPACT_EVERY")) ctx->compact_every = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   if (const char* e = std::getenv("PT_SPLIT_SHADOW")) ctx->split_shadow = std::strtoul(e, nullptr, 10) != 0;
   if (const char* e = std::getenv("PT_TAIL_ENTRIES")) ctx->tail_entries = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
@@ -580,7 +579,7 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
         timed(PT_K_PATHS, [&] {
           ptd::launch_paths(sc, f, st, k & 1u, PT_CNT_QUEUE0 + k % 3u, PT_CNT_QUEUE0 + (k + 1u) % 3u, PT_CNT_QUEUE0 + (k + 2u) % 3u, bound,
                             trace_block < ctx->paths_block_threads ? trace_block : ctx->paths_block_threads, ctx->paths_blocks,
-                            ctx->paths_vertices, ctx->xcd_remap && !sc.scene_in_lds, stream);
+                            ctx->paths_vertices, sc.scene_in_lds ? 0u : ctx->xcd_chunk, stream);
         });
         PT_HIP(ctx, hipGetLastError());
         if ((rc = poll_counts(PT_CNT_QUEUE0 + (k + 1u) % 3u)) != PT_OK) return rc;
@@ -608,7 +607,7 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
           // short queue: every remaining vertex of every queued slot in one k_paths launch
           timed(PT_K_PATHS, [&] {
             ptd::launch_paths(sc, f, st, parity, PT_CNT_QUEUE0 + parity, PT_CNT_QUEUE2, PT_CNT_QUEUE0 + (parity ^ 1u), bound, trace_block,
-                              0xFFFFFFFFu, max_vertices_u32, false, stream);
+                              0xFFFFFFFFu, max_vertices_u32, 0u, stream);
           });
           PT_HIP(ctx, hipGetLastError());
           drained = true;

@@ -1225,17 +1225,21 @@ __global__ __launch_bounds__(256, ALL_OPAQUE ? PT_SHADOW_MIN_WAVES_OPAQUE : PT_S
 template <bool IN_LDS, bool ALL_OPAQUE, int MIN_WAVES>
 __global__ __launch_bounds__(256, MIN_WAVES) void k_paths(pt_dev_scene sc, pt_dev_frame f, pt_dev_state st, uint32_t parity,
                                                                    uint32_t cnt_in, uint32_t cnt_out, uint32_t cnt_zero,
-                                                                   uint32_t max_vertices, uint32_t xcd_remap) {
+                                                                   uint32_t max_vertices, uint32_t xcd_chunk) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
   const uint32_t n = st.counters[cnt_in];
   if (blockIdx.x == 0 && threadIdx.x == 0) st.counters[cnt_zero] = 0;
   Tally ext, tally, walks;
   const uint32_t n_lights = sc.directional_light_count + sc.point_light_count + (f.pc.emissive_triangle_count ? 1u : 0u);
   const vec3 bg_linear = mk(f.bg_linear[0], f.bg_linear[1], f.bg_linear[2]);
-  // Workgroups go to the 8 XCDs round-robin (each with its own 4 MiB L2). With `xcd_remap` (the grid is then a
-  // multiple of 8) XCD x works on the x-th contiguous eighth of the queue, so neighbouring tiles of the image
-  // share an L2 instead of being dealt out over all eight.
-  const uint32_t vblock = xcd_remap ? (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  // Workgroups go to the 8 XCDs round-robin (each with its own 4 MiB L2). With `xcd_chunk` = C > 0 (the grid is
+  // then a multiple of 8 C) the queue is dealt to the XCDs in chunks of C consecutive workgroups, so an XCD's L2
+  // serves neighbouring tiles instead of every eighth one; C = grid / 8 gives each XCD one contiguous eighth.
+  uint32_t vblock = blockIdx.x;
+  if (xcd_chunk) {
+    const uint32_t x = blockIdx.x & 7u, i = blockIdx.x >> 3;
+    vblock = ((i / xcd_chunk) * 8u + x) * xcd_chunk + i % xcd_chunk;
+  }
   if (vblock * blockDim.x < n) {  // block-uniform
     const Tracer tr = make_tracer<IN_LDS>(sc, lds_dyn);
     const ShadeData sd = make_shade_data<IN_LDS>(sc, tr, lds_dyn);
@@ -1366,11 +1370,15 @@ void launch_shade(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_st
 
 void launch_paths(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity, uint32_t cnt_in,
                   uint32_t cnt_out, uint32_t cnt_zero, uint32_t max_entries, uint32_t block, uint32_t max_blocks,
-                  uint32_t max_vertices, bool xcd_remap, hipStream_t s) {
+                  uint32_t max_vertices, uint32_t xcd_chunk, hipStream_t s) {
   uint32_t grid = blocks_for(max_entries, block);
   if (grid > max_blocks) grid = max_blocks;
-  if (xcd_remap) grid = (grid + 7u) & ~7u;
-  const uint32_t remap = xcd_remap ? 1u : 0u;
+  if (xcd_chunk) {  // whole rounds of 8 chunks
+    if (xcd_chunk > (grid + 7u) / 8u) xcd_chunk = (grid + 7u) / 8u;
+    const uint32_t round = 8u * xcd_chunk;
+    grid = (grid + round - 1u) / round * round;
+  }
+  const uint32_t remap = xcd_chunk;
   const size_t lds = shade_lds_bytes(sc, block);
   const int variant = (sc.scene_in_lds ? 2 : 0) | (sc.all_opaque ? 1 : 0);
   // occupancy bound by scene class (swept): 4 waves/SIMD while the scene sits in LDS or in an XCD's L2
