@@ -480,3 +480,65 @@ def rocks_scene(n_tris: int = 5_000_000, seed: int = 20261111, extent: float = 5
     s.camera_lookat = tuple(float(np.float32(x)) for x in look)
     s.camera_vfov = float(np.float32(math.radians(45.0)))
     return s
+
+
+def random_scene(seed: int) -> Scene:
+    """Seeded random small scene for parity fuzzing: a room of quads and boxes with random PBR
+    materials (metal / rough / alpha / emissive, some textured with random filters and wrap
+    modes), 0-2 directional and 0-2 point lights, random camera."""
+    rng = np.random.RandomState(seed)
+    n_tex = int(rng.randint(0, 4))
+    imgs = [default_image()] + [procedural_texture(int(rng.choice([8, 16, 32])), seed * 10 + k, str(rng.choice(["color", "mr", "alpha"])))
+                                for k in range(n_tex)]
+    samplers = np.zeros(1 + n_tex, dtype=abi.SAMPLER)
+    samplers[0] = default_sampler()[0]
+    for k in range(n_tex):
+        samplers[1 + k] = (int(rng.randint(0, 2)), int(rng.randint(0, 2)), int(rng.randint(0, 3)), int(rng.randint(0, 3)))
+    textures = np.zeros(max(1, n_tex + 1), dtype=abi.TEXTURE)
+    for k in range(n_tex):
+        textures[k] = (1 + k, 1 + k)
+    textures[-1] = (0, 0)
+    n_mat = int(rng.randint(2, 7))
+    mats = [default_material()]
+
+    def tex():
+        return int(rng.randint(0, len(textures))) if rng.rand() < 0.4 else -1
+
+    for k in range(n_mat):
+        alpha = 1.0 if rng.rand() < 0.7 else float(np.float32(rng.uniform(0.2, 0.9)))
+        emissive = tuple(float(x) for x in rng.uniform(0.5, 12.0, 3)) if rng.rand() < 0.3 else (0.0, 0.0, 0.0)
+        mats.append(make_material(tuple(float(x) for x in rng.uniform(0.1, 0.95, 3)) + (alpha,),
+                                  metallic=float(rng.choice([0.0, 1.0, rng.uniform(0, 1)])), roughness=float(rng.uniform(0.02, 1.0)),
+                                  emissive=emissive, base_color_texture=tex(), metallic_roughness_texture=tex(),
+                                  occlusion_texture=tex(), occlusion_strength=float(rng.uniform(0, 1)), emissive_texture=tex()))
+    m = _Mesh()
+    m.add_box((-2, -1.5, -2), (2, 1.5, 2), 1 + int(rng.randint(0, n_mat)), inward=True)
+    for _ in range(int(rng.randint(1, 6))):
+        c = rng.uniform(-1.4, 1.4, 3)
+        h = rng.uniform(0.15, 0.6, 3)
+        m.add_box(tuple(c - h), tuple(c + h), 1 + int(rng.randint(0, n_mat)), rot_y=float(rng.uniform(0, 3)))
+    for _ in range(int(rng.randint(0, 4))):
+        c = rng.uniform(-1.5, 1.5, 3)
+        a, b = rng.uniform(-0.8, 0.8, 3), rng.uniform(-0.8, 0.8, 3)
+        n = np.cross(a, b)
+        n /= max(np.linalg.norm(n), 1e-9)
+        m.add(*_quad(tuple(c), tuple(c + a), tuple(c + a + b), tuple(c + b), tuple(n), 1 + int(rng.randint(0, n_mat)),
+                     uv_scale=float(rng.uniform(0.5, 3.0))))
+    kw = {}
+    nd, npnt = int(rng.randint(0, 3)), int(rng.randint(0, 3))
+    dl = np.zeros(nd + 1, dtype=abi.DIRECTIONAL_LIGHT)
+    for k in range(nd):
+        d = rng.normal(size=3)
+        d /= np.linalg.norm(d)
+        dl[k]["color"], dl[k]["intensity"], dl[k]["direction"] = rng.uniform(0.3, 1, 3), float(rng.uniform(0.5, 3)), d
+    pl = np.zeros(npnt + 1, dtype=abi.POINT_LIGHT)
+    for k in range(npnt):
+        pl[k]["color"], pl[k]["intensity"], pl[k]["position"] = rng.uniform(0.3, 1, 3), float(rng.uniform(5, 60)), rng.uniform(-1.5, 1.5, 3)
+    s = m.scene(materials=np.concatenate(mats), images=imgs, samplers=samplers, textures=textures, directional_lights=dl, point_lights=pl)
+    pos = rng.uniform(-1.6, 1.6, 3)
+    look = rng.normal(size=3)
+    look /= np.linalg.norm(look)
+    s.camera_position = tuple(float(np.float32(x)) for x in pos)
+    s.camera_lookat = tuple(float(np.float32(x)) for x in look)
+    s.camera_vfov = float(np.float32(math.radians(rng.uniform(30, 80))))
+    return s

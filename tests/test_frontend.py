@@ -329,3 +329,26 @@ def test_cli_renders_the_readme_config(tmp_path, oracle):
     rp = packed.render_params(oracle, 96, 54, 16, bg, 77, prefix="orc_")
     o_rgba = oracle_lib.render(oracle, packed, rp, threads=4)[0]
     assert np.array_equal(img, o_rgba)
+
+
+@pytest.mark.gpu
+def test_atrium_through_the_glb_front_end(tmp_path, oracle):
+    """cfg3's generator at low tessellation, written as .glb (PNG textures embedded), read back by the C++ loader
+    and rendered by the HIP path: equal to the oracle fed by the same loaded scene."""
+    import oracle_lib
+    from pathtracer_amd.renderer import Renderer
+    glb = tmp_path / "atrium.glb"
+    gltf_export.write_glb(scenes.atrium_scene(detail=2, tex_size=32), str(glb))
+    scene = frontend.load_gltf(str(glb))
+    assert len(scene.images) == 1 + 2 * 22 + 1 and len(scene.directional_lights) == 2
+    r = Renderer(0)
+    try:
+        packed = r.pack(scene)
+        r.upload(packed)
+        rp = packed.render_params(r.lib, 96, 54, 9, (0.5, 0.7, 1.0), 41)
+        rgba, accum, ids, st = r.render_params(rp)
+    finally:
+        r.close()
+    o_rgba, o_accum, o_ids, _ = oracle_lib.render(oracle, packed, rp, threads=8)
+    assert np.array_equal(ids, o_ids) and np.array_equal(accum.view(np.uint32), o_accum.view(np.uint32)) and np.array_equal(rgba, o_rgba)
+    assert st["texture_taps"] > 0

@@ -90,6 +90,12 @@ def test_rocks_cfg4_class_deep_bvh(renderer, oracle):
     compare(renderer, oracle, scenes.rocks_scene(60000), 160, 90, 9, seed=22, bg=(0.5, 0.7, 1.0))
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_random_scenes(renderer, oracle, seed):
+    # fuzz: random materials (metal / rough / alpha / emissive / textured), 0-2 lights of each punctual kind, random camera
+    compare(renderer, oracle, scenes.random_scene(1000 + seed), 64, 40, 9, seed=100 + seed)
+
+
 def test_ragged_resolution_and_single_sample(renderer, oracle):
     # not a multiple of the 8x8 slot tile, portrait, 1 spp
     compare(renderer, oracle, scenes.cornell_scene(with_point_light=True), 37, 53, 1, seed=15)
