@@ -284,6 +284,18 @@ PT_API int pt_build_bvh(const pt_vertex* vertices, uint32_t vertex_count,
                         uint32_t bin_count,
                         pt_bvh_node* nodes_out, uint32_t* node_count_out,
                         uint32_t* depth_out);
+/* The same arrays (nodes, numbering, triangle permutation, depth: bit-identical to
+ * pt_build_bvh with one thread) built by `threads` host threads; SURVEY.md §8f-4, no
+ * counterpart in the reference, whose builder (bvh.cc:36-87) is a sequential recursion.
+ * threads = 0: the machine's hardware threads, at most 16, or $PT_BUILD_THREADS;
+ * threads = 1: the sequential builder. pt_build_bvh itself takes this route from
+ * 65 536 triangles on. Vertex positions must be finite (with NaNs the sequential
+ * builder's result depends on comparison order, which chunked reduction does not keep). */
+PT_API int pt_build_bvh_mt(const pt_vertex* vertices, uint32_t vertex_count,
+                           uint32_t* triangles, uint32_t triangle_count,
+                           uint32_t bin_count,
+                           pt_bvh_node* nodes_out, uint32_t* node_count_out,
+                           uint32_t* depth_out, uint32_t threads);
 
 /* RenderJob::process_scene(), src/renderer/render_job.cc:76-121.  Output capacities:
  * vertex_positions_out 12 floats/triangle, packed_vertex_out 3/triangle,

@@ -48,7 +48,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     srcs = DEVICE_SRC + HOST_SRC + host_extra
     if force or _newer(LIB, srcs):
         extra = os.environ.get("PT_EXTRA_HIPCC_FLAGS", "").split()
-        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", *COMMON, *extra, *srcs, "-o", os.environ.get("PT_LIB_OUT", LIB), "-lz"]
+        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", *COMMON, *extra, *srcs, "-o", os.environ.get("PT_LIB_OUT", LIB), "-lz", "-pthread"]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

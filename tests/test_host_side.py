@@ -75,6 +75,52 @@ def test_builder_and_packing_equal_oracle(ptlib, oracle, name):
         assert bytes(pa) == bytes(pb)
 
 
+def _build(lib, fn, verts, tris, *extra):
+    t = np.ascontiguousarray(tris).copy()
+    nodes = np.zeros(2 * len(t), dtype=abi.BVH_NODE)
+    n, d = C.c_uint32(), C.c_uint32()
+    rc = getattr(lib, fn)(abi.ptr(verts), C.c_uint32(len(verts)), abi.ptr(t), C.c_uint32(len(t)), C.c_uint32(16),
+                          abi.ptr(nodes), C.byref(n), C.byref(d), *extra)
+    assert rc == 0
+    return nodes.tobytes(), t.tobytes(), n.value, d.value
+
+
+def _soup(n, seed, quant=None, signed_zero_axis=None):
+    rng = np.random.RandomState(seed)
+    p = (rng.uniform(-10, 10, (n, 1, 3)) + rng.uniform(-0.3, 0.3, (n, 3, 3))).astype(np.float32)
+    if quant:  # many equal centroids and box faces: ties in every min/max and in the partition
+        p = (np.round(p * quant) / quant).astype(np.float32)
+    if signed_zero_axis is not None:  # a degenerate axis (Q23) made of +0 and -0: min/max must keep the leftmost
+        p[..., signed_zero_axis] = np.float32(0.0) * np.sign(rng.uniform(-1, 1, (n, 3))).astype(np.float32)
+    v = np.zeros(3 * n, dtype=abi.VERTEX)
+    v["position"] = p.reshape(-1, 3)
+    return v, np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+
+
+@pytest.mark.parametrize("case", ["soup", "ties", "signed_zero_plane", "just_above_threshold"])
+def test_threaded_builder_is_bit_identical(ptlib, oracle, case):
+    """nodes, numbering, triangle permutation and depth from 2, 3 and 8 threads equal the
+    sequential builder's and the oracle's recursive restatement."""
+    v, t = {"soup": lambda: _soup(60_000, 1), "ties": lambda: _soup(80_000, 2, quant=2.0),
+            "signed_zero_plane": lambda: _soup(50_000, 3, signed_zero_axis=1), "just_above_threshold": lambda: _soup(4100, 4)}[case]()
+    ref = _build(ptlib, "pt_build_bvh_mt", v, t, C.c_uint32(1))
+    assert ref == _build(oracle, "orc_build_bvh", v, t)
+    for threads in (2, 3, 8):
+        assert _build(ptlib, "pt_build_bvh_mt", v, t, C.c_uint32(threads)) == ref
+    if case == "ties":  # 80 000 triangles: pt_build_bvh itself takes the threaded route
+        assert _build(ptlib, "pt_build_bvh", v, t) == ref
+
+
+def test_threaded_builder_soup_kat(ptlib, monkeypatch):
+    """The reference's own 20 000-triangle known answer through the threaded route."""
+    class Threaded:  # PackedScene calls <prefix>build_bvh: route it through pt_build_bvh_mt with 4 threads
+        def __getattr__(self, name):
+            if name == "pt_build_bvh":
+                return lambda *a: ptlib.pt_build_bvh_mt(*a, C.c_uint32(4))
+            return getattr(ptlib, name)
+    check_soup(Threaded(), "pt_")
+
+
 def test_builder_rejects_bad_input(ptlib):
     s = scenes.cube_scene()
     tris = np.ascontiguousarray(s.triangles).copy()
