@@ -326,10 +326,11 @@ extern "C" int pt_upload_scene(pt_ctx* ctx, const pt_scene_desc* s) {
   pt_dev_scene d{};
   const size_t ntri = s->triangle_count;
   static_assert(sizeof(pt_packed_bvh_node) == 32 && sizeof(pt_material) == 64, "layout");
-  // Child-pair records in breadth-first order: record p of inner node N is
-  // {left.min, left.ref | left.max, left.cnt | right.min, right.ref | right.max, right.cnt},
-  // ref = the child's own record (inner) or its first triangle (leaf). Boxes and triangle
-  // ranges are copied bit for bit from the reference array; only the addressing changes.
+  // Child-pair records in breadth-first order: record p of inner node N is four quads
+  // {lmin.x, rmin.x, lmin.y, rmin.y | lmin.z, rmin.z, lmax.x, rmax.x | lmax.y, rmax.y, lmax.z, rmax.z |
+  //  left.ref, left.cnt, right.ref, right.cnt}, ref = the child's own record (inner) or its first
+  // triangle (leaf). Boxes and triangle ranges are copied bit for bit from the reference array; only the
+  // addressing and the order of the words change (left/right interleaved for the packed slab test).
   {
     const pt_packed_bvh_node* N = s->bvh_nodes;
     std::vector<uint32_t> order;  // inner nodes, breadth-first
@@ -344,13 +345,22 @@ extern "C" int pt_upload_scene(pt_ctx* ctx, const pt_scene_desc* s) {
       }
     }
     // record_of[] of a child is assigned when the child is dequeued, i.e. after its parent: two passes
-    std::vector<pt_packed_bvh_node> rec(2 * order.size());
+    struct PairRecord {
+      float box[12];
+      uint32_t child[4];
+    };
+    static_assert(sizeof(PairRecord) == 64, "layout");
+    std::vector<PairRecord> rec(order.size());
     for (size_t p = 0; p < order.size(); ++p) {
       for (uint32_t side = 0; side < 2; ++side) {
         const uint32_t c = N[order[p]].left_or_begin + side;
-        pt_packed_bvh_node r = N[c];
-        if (r.triangle_count == 0) r.left_or_begin = record_of[c];
-        rec[2 * p + side] = r;
+        const pt_packed_bvh_node& r = N[c];
+        for (int k = 0; k < 3; ++k) {
+          rec[p].box[2 * k + side] = r.aabb_min[k];
+          rec[p].box[6 + 2 * k + side] = r.aabb_max[k];
+        }
+        rec[p].child[2 * side] = r.triangle_count == 0 ? record_of[c] : r.left_or_begin;
+        rec[p].child[2 * side + 1] = r.triangle_count;
       }
     }
     d.pair_count = static_cast<uint32_t>(order.size());

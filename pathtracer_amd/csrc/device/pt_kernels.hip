@@ -164,14 +164,15 @@ struct Hit {
 // count after this cull (the oracle's ORC_FLAG_CULL_BEHIND mirrors it).
 typedef float f2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ void ray_box_pair(vec3 o, vec3 inv, const float4& lmin, const float4& lmax, const float4& rmin,
-                                             const float4& rmax, float t_best, bool& hit_l, bool& hit_r, float& dist_l,
-                                             float& dist_r) {
+__device__ __forceinline__ void ray_box_pair(vec3 o, vec3 inv, const float4& q0, const float4& q1, const float4& q2, float t_best,
+                                             bool& hit_l, bool& hit_r, float& dist_l, float& dist_r) {
+  // q0 = {lmin.x, rmin.x, lmin.y, rmin.y}, q1 = {lmin.z, rmin.z, lmax.x, rmax.x}, q2 = {lmax.y, rmax.y, lmax.z, rmax.z}:
+  // every {left, right} operand pair of the packed instructions is an aligned register pair as loaded
   const f2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
   const f2 ix = {inv.x, inv.x}, iy = {inv.y, inv.y}, iz = {inv.z, inv.z};
-  const f2 ax = ix * (f2{lmin.x, rmin.x} - ox), bx = ix * (f2{lmax.x, rmax.x} - ox);  // t_min.x, t_max.x of {L, R}
-  const f2 ay = iy * (f2{lmin.y, rmin.y} - oy), by = iy * (f2{lmax.y, rmax.y} - oy);
-  const f2 az = iz * (f2{lmin.z, rmin.z} - oz), bz = iz * (f2{lmax.z, rmax.z} - oz);
+  const f2 ax = ix * (f2{q0.x, q0.y} - ox), bx = ix * (f2{q1.z, q1.w} - ox);  // t_min.x, t_max.x of {L, R}
+  const f2 ay = iy * (f2{q0.z, q0.w} - oy), by = iy * (f2{q2.x, q2.y} - oy);
+  const f2 az = iz * (f2{q1.x, q1.y} - oz), bz = iz * (f2{q2.z, q2.w} - oz);
   const float near_l = gmax(gmax(gmin(ax.x, bx.x), gmin(ay.x, by.x)), gmin(az.x, bz.x));
   const float far_l = gmin(gmin(gmax(ax.x, bx.x), gmax(ay.x, by.x)), gmax(az.x, bz.x));
   const float near_r = gmax(gmax(gmin(ax.y, bx.y), gmin(ay.y, by.y)), gmin(az.y, bz.y));
@@ -184,8 +185,11 @@ __device__ __forceinline__ void ray_box_pair(vec3 o, vec3 inv, const float4& lmi
 
 // Where a traversal reads the scene from. The BVH is held as CHILD-PAIR records in
 // breadth-first order (built at upload from the reference's node array, pt_context.hip):
-// record p = {left.min, left.ref | left.max, left.cnt | right.min, right.ref | right.max,
-// right.cnt}, 64 bytes, where ref is the child's own pair record (inner) or its first
+// record p = four quads, 64 bytes:
+//   {lmin.x, rmin.x, lmin.y, rmin.y | lmin.z, rmin.z, lmax.x, rmax.x | lmax.y, rmax.y, lmax.z, rmax.z |
+//    left.ref, left.cnt, right.ref, right.cnt}
+// (left/right interleaved: the slab test runs left and right in the two halves of packed
+// fp32 instructions), where ref is the child's own pair record (inner) or its first
 // triangle (leaf). IN_LDS: the scene (records + triangle positions) is small enough to be
 // staged whole in the workgroup's LDS and every fetch is a ds_read_b128; otherwise the
 // fetches are global loads (L1/L2/Infinity Cache/HBM).
@@ -193,9 +197,13 @@ struct Tracer {
   const float4* pairs;    // LDS or global, breadth-first
   const float4* tri_pos;  // LDS or global, 3 x float4 per triangle
   uint32_t root_ref, root_cnt;
-  uint32_t* stack;        // this lane's column of the LDS stack
-  uint32_t stride;
+  uint32_t stack;         // LDS byte address of this lane's column of the traversal stack
+  uint32_t stride;        // bytes from one level to the next
 };
+
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+__device__ __forceinline__ void stack_store(uint32_t addr, uint32_t v) { *reinterpret_cast<lds_u32*>(static_cast<uintptr_t>(addr)) = v; }
+__device__ __forceinline__ uint32_t stack_load(uint32_t addr) { return *reinterpret_cast<lds_u32*>(static_cast<uintptr_t>(addr)); }
 
 template <bool IN_LDS>
 __device__ __forceinline__ float4 fetch16(const float4* base, uint32_t index) {
@@ -209,6 +217,22 @@ __device__ __forceinline__ float4 fetch16(const float4* base, uint32_t index) {
   }
 #endif
   return base[index];
+}
+
+// (ref, cnt) of side 0/1 of pair record `rec`: one 8-byte fetch from the record's last quad
+template <bool IN_LDS>
+__device__ __forceinline__ uint2 fetch_child(const float4* pairs, uint32_t rec, uint32_t side) {
+  const uint32_t index = 8u * rec + 6u + side;  // in 8-byte units
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (IN_LDS) {
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    typedef const __attribute__((address_space(3))) u2 lds_u2;
+    lds_u2* p = (lds_u2*)(uintptr_t)static_cast<uint32_t>(reinterpret_cast<uintptr_t>(pairs));
+    const u2 v = p[index];
+    return make_uint2(v.x, v.y);
+  }
+#endif
+  return reinterpret_cast<const uint2*>(pairs)[index];
 }
 
 // ray_triangle_intersect, main.comp:189-217
@@ -260,37 +284,37 @@ template <bool IN_LDS, bool ANY_HIT>
 __device__ __forceinline__ void traverse(const Tracer& tr, vec3 o, vec3 d, Hit& h, Tally& tally) {
   ++tally.rays;
   const vec3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-  uint32_t sp = 0;
+  uint32_t sp = tr.stack;      // LDS address of the next free stack entry
   uint32_t ref = tr.root_ref;  // root: never box-tested (Q13)
   uint32_t cnt = tr.root_cnt;
   bool live = true;
   // pop the next deferred child into (ref, cnt), or end the traversal
   auto pop = [&]() {
-    if (sp == 0) {
+    if (sp == tr.stack) {
       live = false;
       return;
     }
-    --sp;
-    const uint32_t e = tr.stack[sp * tr.stride];
-    const uint32_t word = 4u * (e >> 1) + 2u * (e & 1u);
-    ref = fbits(fetch16<IN_LDS>(tr.pairs, word).w);
-    cnt = fbits(fetch16<IN_LDS>(tr.pairs, word + 1u).w);
+    sp -= tr.stride;
+    const uint32_t e = stack_load(sp);
+    const uint2 c = fetch_child<IN_LDS>(tr.pairs, e >> 1, e & 1u);
+    ref = c.x;
+    cnt = c.y;
   };
   auto inner = [&]() {
     ++tally.visits;
-    const float4 l0 = fetch16<IN_LDS>(tr.pairs, 4 * ref), l1 = fetch16<IN_LDS>(tr.pairs, 4 * ref + 1);
-    const float4 r0 = fetch16<IN_LDS>(tr.pairs, 4 * ref + 2), r1 = fetch16<IN_LDS>(tr.pairs, 4 * ref + 3);
+    const float4 q0 = fetch16<IN_LDS>(tr.pairs, 4 * ref), q1 = fetch16<IN_LDS>(tr.pairs, 4 * ref + 1);
+    const float4 q2 = fetch16<IN_LDS>(tr.pairs, 4 * ref + 2), q3 = fetch16<IN_LDS>(tr.pairs, 4 * ref + 3);
     float dist_l, dist_r;
     bool hit_l, hit_r;
-    ray_box_pair(o, inv, l0, l1, r0, r1, h.t, hit_l, hit_r, dist_l, dist_r);
+    ray_box_pair(o, inv, q0, q1, q2, h.t, hit_l, hit_r, dist_l, dist_r);
     if (hit_l || hit_r) {
       const bool go_left = hit_l && (!hit_r || dist_l < dist_r);  // equal distances: right is near (Q14)
       if (hit_l && hit_r) {
-        tr.stack[sp * tr.stride] = (ref << 1) | (go_left ? 1u : 0u);  // the far side
-        ++sp;
+        stack_store(sp, (ref << 1) | (go_left ? 1u : 0u));  // the far side
+        sp += tr.stride;
       }
-      ref = go_left ? fbits(l0.w) : fbits(r0.w);
-      cnt = go_left ? fbits(l1.w) : fbits(r1.w);
+      ref = go_left ? fbits(q3.x) : fbits(q3.z);
+      cnt = go_left ? fbits(q3.y) : fbits(q3.w);
     } else {
       pop();
     }
@@ -330,28 +354,28 @@ __device__ __forceinline__ void traverse(const Tracer& tr, vec3 o, vec3 d, Hit& 
         }
       } else {
         ++tally.visits;
-        const float4 l0 = fetch16<IN_LDS>(tr.pairs, 4 * ref), l1 = fetch16<IN_LDS>(tr.pairs, 4 * ref + 1);
-        const float4 r0 = fetch16<IN_LDS>(tr.pairs, 4 * ref + 2), r1 = fetch16<IN_LDS>(tr.pairs, 4 * ref + 3);
+        const float4 q0 = fetch16<IN_LDS>(tr.pairs, 4 * ref), q1 = fetch16<IN_LDS>(tr.pairs, 4 * ref + 1);
+        const float4 q2 = fetch16<IN_LDS>(tr.pairs, 4 * ref + 2), q3 = fetch16<IN_LDS>(tr.pairs, 4 * ref + 3);
         float dist_l, dist_r;
         bool hit_l, hit_r;
-        ray_box_pair(o, inv, l0, l1, r0, r1, h.t, hit_l, hit_r, dist_l, dist_r);
+        ray_box_pair(o, inv, q0, q1, q2, h.t, hit_l, hit_r, dist_l, dist_r);
         if (hit_l || hit_r) {
           const bool go_left = hit_l && (!hit_r || dist_l < dist_r);
           if (hit_l && hit_r) {
-            tr.stack[sp * tr.stride] = (ref << 1) | (go_left ? 1u : 0u);
-            ++sp;
+            stack_store(sp, (ref << 1) | (go_left ? 1u : 0u));
+            sp += tr.stride;
           }
-          ref = go_left ? fbits(l0.w) : fbits(r0.w);
-          cnt = go_left ? fbits(l1.w) : fbits(r1.w);
+          ref = go_left ? fbits(q3.x) : fbits(q3.z);
+          cnt = go_left ? fbits(q3.y) : fbits(q3.w);
           continue;
         }
       }
-      if (sp == 0) break;
-      --sp;
-      const uint32_t e = tr.stack[sp * tr.stride];
-      const uint32_t word = 4u * (e >> 1) + 2u * (e & 1u);
-      ref = fbits(fetch16<IN_LDS>(tr.pairs, word).w);
-      cnt = fbits(fetch16<IN_LDS>(tr.pairs, word + 1u).w);
+      if (sp == tr.stack) break;
+      sp -= tr.stride;
+      const uint32_t e = stack_load(sp);
+      const uint2 c = fetch_child<IN_LDS>(tr.pairs, e >> 1, e & 1u);
+      ref = c.x;
+      cnt = c.y;
     }
   }
 }
@@ -374,8 +398,8 @@ __device__ __forceinline__ Tracer make_tracer(const pt_dev_scene& sc, uint32_t* 
   }
   tr.root_ref = sc.root_ref;
   tr.root_cnt = sc.root_cnt;
-  tr.stack = lds + threadIdx.x;
-  tr.stride = blockDim.x;
+  tr.stack = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds + threadIdx.x));  // flat LDS address -> LDS offset (its low 32 bits)
+  tr.stride = 4u * blockDim.x;
   return tr;
 }
 
