@@ -453,7 +453,9 @@ extern "C" int pt_upload_scene(pt_ctx* ctx, const pt_scene_desc* s) {
   // is staged whole in every traversal workgroup's LDS (next to the 1 KiB-per-level stack).
   d.scene_in_lds = (64ull * d.pair_count + (48ull + 64ull) * s->triangle_count + 64ull * s->material_count +
                         32ull * (s->directional_light_count + s->point_light_count) + 4ull * s->emissive_triangle_count <=
-                    ctx->lds_scene_bytes) ? 1u : 0u;
+                    ctx->lds_scene_bytes &&
+                    d.pair_count < 65536u && s->triangle_count < 65536u)  // LDS stack entries pack (ref << 16 | cnt)
+                       ? 1u : 0u;
   PT_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
   PT_HIP(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors die here
   float ms = 0.0f;
