@@ -443,6 +443,13 @@ extern "C" int pt_upload_scene(pt_ctx* ctx, const pt_scene_desc* s) {
       }
     }
   }
+  d.any_texture = 0;
+  for (uint32_t i = 0; i < s->material_count; ++i) {
+    const pt_material& m = s->materials[i];
+    if (m.base_color_texture_index != -1 || m.metallic_roughness_texture_index != -1 || m.emissive_texture_index != -1 ||
+        m.occlusion_texture_index != -1)
+      d.any_texture = 1;
+  }
   d.directional_light_count = s->directional_light_count;
   d.point_light_count = s->point_light_count;
   d.stack_entries = depth + 1;

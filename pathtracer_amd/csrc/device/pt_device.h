@@ -45,6 +45,7 @@ struct pt_dev_scene {
   uint32_t root_ref, root_cnt;       // the root as a child reference: pair 0 (count 0) or a leaf's triangle range
   uint32_t scene_in_lds;             // 1: the scene (pair records, triangle positions; for shading also attributes, materials, lights, emitter list) is staged whole in the workgroup's LDS
   uint32_t all_opaque;               // 1: no surface can report alpha != 1 (shadow rays may stop at the first hit)
+  uint32_t any_texture;              // 0: no material names a texture (kernels without sampling code)
 };
 
 struct pt_dev_frame {

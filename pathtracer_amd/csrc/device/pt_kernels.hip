@@ -768,7 +768,7 @@ __global__ __launch_bounds__(256) void k_extend(pt_dev_scene sc, pt_dev_state st
 
 // ray_scene_intersect_with_transparency, main.comp:306-332. Returns the transparency and
 // leaves the last traversal's result in h.
-template <bool IN_LDS, bool ALL_OPAQUE>
+template <bool IN_LDS, bool ALL_OPAQUE, bool TEXTURED = true>
 __device__ __forceinline__ float shadow_walk(const pt_dev_scene& sc, const ShadeData& sd, const Tracer& tr, vec3 origin, vec3 dir,
                                              Hit& h, Tally& tally) {
   float transparency = 1.0f;
@@ -789,7 +789,7 @@ __device__ __forceinline__ float shadow_walk(const pt_dev_scene& sc, const Shade
     uint32_t mat_idx;
     interpolate_pos_uv<IN_LDS>(sd, h.tri, wuv, pos, tu, tv, mat_idx, nullptr, tally);
     const float4 base = fetch16<IN_LDS>(sd.materials, 4 * mat_idx);
-    const int base_tex = static_cast<int>(fbits(fetch16<IN_LDS>(sd.materials, 4 * mat_idx + 1).x));
+    const int base_tex = TEXTURED ? static_cast<int>(fbits(fetch16<IN_LDS>(sd.materials, 4 * mat_idx + 1).x)) : -1;
     const float alpha = base.w * sample_texture(sc, base_tex, tu, tv, tally).w;
     if (alpha == 1.0f) return 0.0f;  // any opaque closest hit, at any distance (Q5)
     transparency *= 1.0f - alpha;
@@ -819,7 +819,7 @@ struct PathRegs {
 // ran 2x slower per ray inside the 128..168-register shading kernel). `shaded` tells the
 // caller to queue the slot for k_shadow. The deferred arithmetic is the same expressions in
 // the same order, so results stay bit-identical to the fused form.
-template <bool IN_LDS, bool ALL_OPAQUE, bool SPLIT>
+template <bool IN_LDS, bool ALL_OPAQUE, bool SPLIT, bool PUNCTUAL = true, bool TEXTURED = true>
 __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const ShadeData& sd, const pt_dev_frame& f, const pt_dev_state& st,
                                              const Tracer& tr, uint32_t n_lights, vec3 bg_linear, uint32_t slot,
                                              const Hit& hit, vec3 ray_dir, PathRegs& p, vec3& next_o, vec3& next_d,
@@ -844,7 +844,8 @@ __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const Shade
     if (dot(nrm, ray_dir) > 0.0f) nrm = nrm * -1.0f;  // main.comp:524
 
     // get_material_data, main.comp:242-259
-    const Material m = load_material<IN_LDS>(sd.materials, mat_idx);
+    Material m = load_material<IN_LDS>(sd.materials, mat_idx);
+    if (!TEXTURED) m.base_tex = m.mr_tex = m.emissive_tex = m.occlusion_tex = -1;  // no material names a texture: the sampling code folds away
     const float4 bc = sample_texture(sc, m.base_tex, tu, tv, tally);
     const vec3 base_color = mk(m.base_color.x, m.base_color.y, m.base_color.z) * decode_srgb(m.base_tex, bc);
     const float alpha = m.base_color.w * bc.w;
@@ -877,7 +878,8 @@ __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const Shade
       uint32_t etri = 0;
       vec3 ewuv = splat(0.0f);
       float4 q0 = l0, q1 = l0, q2 = l0;
-      const uint32_t kind = j < n_dir ? 0u : (j < n_punctual ? 1u : 2u);
+      // PUNCTUAL = false: the scene has no directional or point light, every sample is the area sample
+      const uint32_t kind = !PUNCTUAL ? 2u : (j < n_dir ? 0u : (j < n_punctual ? 1u : 2u));
       if (kind == 0u) {
         l0 = fetch16<IN_LDS>(sd.dlights, 2 * j);
         l = -xyz(fetch16<IN_LDS>(sd.dlights, 2 * j + 1));
@@ -937,7 +939,8 @@ __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const Shade
             const float area = length(cross(xyz(q1) - xyz(q0), xyz(q2) - xyz(q0))) / 2.0f;
             const float cos_theta0 = dot(tri_n, -l);
             pdf = dist2 / (cos_theta0 * area) / static_cast<float>(f.pc.emissive_triangle_count);
-            const Material emat = load_material<IN_LDS>(sd.materials, at.mat);
+            Material emat = load_material<IN_LDS>(sd.materials, at.mat);
+            if (!TEXTURED) emat.emissive_tex = -1;
             Tally uncounted;  // the reference fetches the emitter's texture only for visible samples: k_shadow counts the tap
             const float4 et = sample_texture(sc, emat.emissive_tex, eu, ev, uncounted);
             tap_if_visible = emat.emissive_tex != -1 ? 1u : 0u;
@@ -966,7 +969,7 @@ __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const Shade
           continue;
         }
       }
-      const float transparency = shadow_walk<IN_LDS, ALL_OPAQUE>(sc, sd, tr, shadow_origin, l, sh, walks);
+      const float transparency = shadow_walk<IN_LDS, ALL_OPAQUE, TEXTURED>(sc, sd, tr, shadow_origin, l, sh, walks);
       if (transparency == 0.0f) continue;
       if (kind != 0u) {
         const float correction = kNormalDelta / dot(l, nrm);
@@ -992,7 +995,8 @@ __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const Shade
         const float cos_theta0 = dot(tri_n, -l);
         const float pdf = dist2 / (cos_theta0 * area) / static_cast<float>(f.pc.emissive_triangle_count);
         const float n_dot_l = __builtin_fabsf(dot(nrm, l));
-        const Material emat = load_material<IN_LDS>(sd.materials, at.mat);
+        Material emat = load_material<IN_LDS>(sd.materials, at.mat);
+            if (!TEXTURED) emat.emissive_tex = -1;
         const float4 et = sample_texture(sc, emat.emissive_tex, eu, ev, tally);
         const vec3 e_emission = emat.emissive * decode_srgb(emat.emissive_tex, et) * transparency;
         area_light = e_emission * microfacet_brdf(nrm, view, l, metal, a2, base_color) * n_dot_l / pdf;
@@ -1010,7 +1014,8 @@ __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const Shade
       deferred_origin = shadow_origin;
     }
 
-    if (alpha < 1.0f && transp_steps < kMaxTransparencySteps) {  // main.comp:542-547
+    // (a provably all-opaque scene has alpha == 1.0f at every vertex: the pass-through arm is dead)
+    if (!ALL_OPAQUE && alpha < 1.0f && transp_steps < kMaxTransparencySteps) {  // main.comp:542-547
       ++transp_steps;
       if (SPLIT) alpha_factor = alpha;
       else color = color + direct * alpha * indirect;
@@ -1253,7 +1258,7 @@ __global__ __launch_bounds__(256, ALL_OPAQUE ? PT_SHADOW_MIN_WAVES_OPAQUE : PT_S
 // Queue counters rotate over three words: this launch reads `cnt_in`, appends to `cnt_out` and
 // clears `cnt_zero` (the previous launch's input, the next launch's output) — no launch
 // clears a word that blocks of the same launch still have to read.
-template <bool IN_LDS, bool ALL_OPAQUE, int MIN_WAVES>
+template <bool IN_LDS, bool ALL_OPAQUE, int MIN_WAVES, bool PUNCTUAL, bool TEXTURED>
 __global__ __launch_bounds__(256, MIN_WAVES) void k_paths(pt_dev_scene sc, pt_dev_frame f, pt_dev_state st, uint32_t parity,
                                                                    uint32_t cnt_in, uint32_t cnt_out, uint32_t cnt_zero,
                                                                    uint32_t max_vertices, uint32_t xcd_chunk) {
@@ -1293,8 +1298,8 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_paths(pt_dev_scene sc, pt_de
           primary = false;
           vec3 next_o = mk(0, 0, 0), next_d = mk(0, 0, 0);
           bool shaded;
-          alive = shade_vertex<IN_LDS, ALL_OPAQUE, false>(sc, sd, f, st, tr, n_lights, bg_linear, slot, h, d, p, next_o, next_d, tally,
-                                                          walks, shaded);
+          alive = shade_vertex<IN_LDS, ALL_OPAQUE, false, PUNCTUAL, TEXTURED>(sc, sd, f, st, tr, n_lights, bg_linear, slot, h, d, p,
+                                                                              next_o, next_d, tally, walks, shaded);
           if (!alive) break;
           o = next_o;
           d = next_d;
@@ -1415,20 +1420,32 @@ void launch_paths(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_st
   // occupancy bound by scene class (swept): 4 waves/SIMD while the scene sits in LDS or in an XCD's L2
   // (VALU bound: spills cost more than a 5th wave hides), 5 once its fetches go to the Infinity Cache / HBM
   const bool big = !sc.scene_in_lds && 64ull * sc.pair_count + 48ull * sc.triangle_count > (4ull << 20);
-#define PT_LAUNCH_PATHS(A, B, W) \
-  hipLaunchKernelGGL((k_paths<A, B, W>), dim3(grid), dim3(block), lds, s, sc, f, st, parity, cnt_in, cnt_out, cnt_zero, max_vertices, remap)
+  // Kernels specialised on what the scene provably lacks (dead code and its registers go: cfg2 +4.8 % without the
+  // punctual-light arms; LDS scenes only — the others wait on memory): no directional or point light -> the light
+  // loop is the area sample alone; no material names a texture -> no sampling code.
+  const bool punctual = sc.directional_light_count + sc.point_light_count != 0;
+  const bool textured = sc.any_texture != 0;
+#define PT_LAUNCH_PATHS(A, B, W, P, T) \
+  hipLaunchKernelGGL((k_paths<A, B, W, P, T>), dim3(grid), dim3(block), lds, s, sc, f, st, parity, cnt_in, cnt_out, cnt_zero, max_vertices, remap)
+#define PT_LAUNCH_PATHS_LDS(B)                                                     \
+  do {                                                                             \
+    if (textured) PT_LAUNCH_PATHS(true, B, PT_PATHS_MIN_WAVES, true, true);        \
+    else if (punctual) PT_LAUNCH_PATHS(true, B, PT_PATHS_MIN_WAVES, true, false);  \
+    else PT_LAUNCH_PATHS(true, B, PT_PATHS_MIN_WAVES, false, false);               \
+  } while (0)
   switch (variant) {
-    case 3: PT_LAUNCH_PATHS(true, true, PT_PATHS_MIN_WAVES); break;
-    case 2: PT_LAUNCH_PATHS(true, false, PT_PATHS_MIN_WAVES); break;
+    case 3: PT_LAUNCH_PATHS_LDS(true); break;
+    case 2: PT_LAUNCH_PATHS_LDS(false); break;
     case 1:
-      if (big) PT_LAUNCH_PATHS(false, true, PT_PATHS_MIN_WAVES_GLOBAL);
-      else PT_LAUNCH_PATHS(false, true, PT_PATHS_MIN_WAVES);
+      if (big) PT_LAUNCH_PATHS(false, true, PT_PATHS_MIN_WAVES_GLOBAL, true, true);
+      else PT_LAUNCH_PATHS(false, true, PT_PATHS_MIN_WAVES, true, true);
       break;
     default:
-      if (big) PT_LAUNCH_PATHS(false, false, PT_PATHS_MIN_WAVES_GLOBAL);
-      else PT_LAUNCH_PATHS(false, false, PT_PATHS_MIN_WAVES);
+      if (big) PT_LAUNCH_PATHS(false, false, PT_PATHS_MIN_WAVES_GLOBAL, true, true);
+      else PT_LAUNCH_PATHS(false, false, PT_PATHS_MIN_WAVES, true, true);
       break;
   }
+#undef PT_LAUNCH_PATHS_LDS
 #undef PT_LAUNCH_PATHS
 }
 
