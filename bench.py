@@ -236,6 +236,10 @@ def main() -> None:
             ceiling = 11100.0 if scene_bytes <= (4 << 20) else (4400.0 if scene_bytes <= (48 << 20) else 3550.0)
             roof["random_gather_ceiling_gbs"] = ceiling
             roof["frac_of_gather_ceiling"] = roof["achieved"] / ceiling
+        else:
+            # LDS-resident scene: the algorithmic bytes are read from each workgroup's LDS copy, not from HBM, so this
+            # fraction of the HBM peak can pass 1; what reaches memory is `traffic`, what binds is VALU issue (`valu`)
+            roof["served_from"] = "lds"
         traffic_file = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
         if os.path.exists(traffic_file) and not args.spp:
             # HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same command (scripts/pmc_passes.sh)

@@ -871,7 +871,8 @@ __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const Shade
     vec3 punctual = splat(0.0f);
     vec3 area_light = splat(0.0f);
     const uint32_t n_dir = sc.directional_light_count, n_punctual = n_dir + sc.point_light_count;
-    for (uint32_t j = 0; j < n_lights; ++j) {
+    const uint32_t n_samples = PUNCTUAL ? n_lights : (n_lights != 0u ? 1u : 0u);  // !PUNCTUAL: at most one trip, no back edge
+    for (uint32_t j = 0; j < n_samples; ++j) {
       vec3 l, sample_pos = splat(0.0f), sample_dir = splat(0.0f);
       float4 l0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
       float dist2 = 0.0f;
