@@ -1103,6 +1103,9 @@ __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const Shade
 #ifndef PT_PATHS_MIN_WAVES
 #define PT_PATHS_MIN_WAVES 4
 #endif
+#ifndef PT_PATHS_MIN_WAVES_PLAIN
+#define PT_PATHS_MIN_WAVES_PLAIN PT_PATHS_MIN_WAVES
+#endif
 #ifndef PT_PATHS_MIN_WAVES_GLOBAL
 #define PT_PATHS_MIN_WAVES_GLOBAL 5  // scenes beyond an XCD's L2: swept 3..6 on cfg3/cfg4-class scenes, best at 5
 #endif
@@ -1432,7 +1435,7 @@ void launch_paths(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_st
   do {                                                                             \
     if (textured) PT_LAUNCH_PATHS(true, B, PT_PATHS_MIN_WAVES, true, true);        \
     else if (punctual) PT_LAUNCH_PATHS(true, B, PT_PATHS_MIN_WAVES, true, false);  \
-    else PT_LAUNCH_PATHS(true, B, PT_PATHS_MIN_WAVES, false, false);               \
+    else PT_LAUNCH_PATHS(true, B, PT_PATHS_MIN_WAVES_PLAIN, false, false);         \
   } while (0)
   switch (variant) {
     case 3: PT_LAUNCH_PATHS_LDS(true); break;
