@@ -482,12 +482,14 @@ def rocks_scene(n_tris: int = 5_000_000, seed: int = 20261111, extent: float = 5
     return s
 
 
-def random_scene(seed: int) -> Scene:
+def random_scene(seed: int, with_textures: bool = True, with_punctual: bool = True, with_alpha: bool = True) -> Scene:
     """Seeded random small scene for parity fuzzing: a room of quads and boxes with random PBR
     materials (metal / rough / alpha / emissive, some textured with random filters and wrap
-    modes), 0-2 directional and 0-2 point lights, random camera."""
+    modes), 0-2 directional and 0-2 point lights, random camera. The three switches take
+    textures, punctual lights or non-opaque materials out, so that every kernel
+    specialisation gets its own scenes."""
     rng = np.random.RandomState(seed)
-    n_tex = int(rng.randint(0, 4))
+    n_tex = int(rng.randint(0, 4)) if with_textures else 0
     imgs = [default_image()] + [procedural_texture(int(rng.choice([8, 16, 32])), seed * 10 + k, str(rng.choice(["color", "mr", "alpha"])))
                                 for k in range(n_tex)]
     samplers = np.zeros(1 + n_tex, dtype=abi.SAMPLER)
@@ -502,12 +504,14 @@ def random_scene(seed: int) -> Scene:
     mats = [default_material()]
 
     def tex():
-        return int(rng.randint(0, len(textures))) if rng.rand() < 0.4 else -1
+        pick = int(rng.randint(0, len(textures))) if rng.rand() < 0.4 else -1
+        return pick if n_tex else -1
 
     for k in range(n_mat):
-        alpha = 1.0 if rng.rand() < 0.7 else float(np.float32(rng.uniform(0.2, 0.9)))
+        a = 1.0 if rng.rand() < 0.7 else float(np.float32(rng.uniform(0.2, 0.9)))
+        a = a if with_alpha else 1.0
         emissive = tuple(float(x) for x in rng.uniform(0.5, 12.0, 3)) if rng.rand() < 0.3 else (0.0, 0.0, 0.0)
-        mats.append(make_material(tuple(float(x) for x in rng.uniform(0.1, 0.95, 3)) + (alpha,),
+        mats.append(make_material(tuple(float(x) for x in rng.uniform(0.1, 0.95, 3)) + (a,),
                                   metallic=float(rng.choice([0.0, 1.0, rng.uniform(0, 1)])), roughness=float(rng.uniform(0.02, 1.0)),
                                   emissive=emissive, base_color_texture=tex(), metallic_roughness_texture=tex(),
                                   occlusion_texture=tex(), occlusion_strength=float(rng.uniform(0, 1)), emissive_texture=tex()))
@@ -526,6 +530,8 @@ def random_scene(seed: int) -> Scene:
                      uv_scale=float(rng.uniform(0.5, 3.0))))
     kw = {}
     nd, npnt = int(rng.randint(0, 3)), int(rng.randint(0, 3))
+    if not with_punctual:
+        nd = npnt = 0
     dl = np.zeros(nd + 1, dtype=abi.DIRECTIONAL_LIGHT)
     for k in range(nd):
         d = rng.normal(size=3)

@@ -96,6 +96,15 @@ def test_random_scenes(renderer, oracle, seed):
     compare(renderer, oracle, scenes.random_scene(1000 + seed), 64, 40, 9, seed=100 + seed)
 
 
+@pytest.mark.parametrize("textures,punctual,alpha", [(t, p, a) for t in (False, True) for p in (False, True) for a in (False, True)])
+def test_every_kernel_specialisation(renderer, oracle, textures, punctual, alpha):
+    # k_paths is instantiated per scene class (opaque or not) x (textured | punctual lights only | area light only):
+    # two seeded scenes of each of the eight switch settings
+    for seed in (7, 8):
+        s = scenes.random_scene(2000 + seed, with_textures=textures, with_punctual=punctual, with_alpha=alpha)
+        compare(renderer, oracle, s, 48, 32, 9, seed=seed)
+
+
 def test_ragged_resolution_and_single_sample(renderer, oracle):
     # not a multiple of the 8x8 slot tile, portrait, 1 spp
     compare(renderer, oracle, scenes.cornell_scene(with_point_light=True), 37, 53, 1, seed=15)
