@@ -64,3 +64,13 @@ def test_hip_reproduces_golden(name):
     # kernels' two result-preserving culls and are checked against the oracle's checker mode elsewhere
     for k in ("paths", "rays", "texture_taps", "shaded_vertices", "nan_samples"):
         assert st[k] == int(g["counters"][make_golden.COUNTERS.index(k)]), k
+
+
+def test_cfg2_full_digest_fixture_is_self_consistent():
+    """The committed full-size oracle digest of BASELINE configs[1] (make_cfg2_digest.py): shape, sample count and
+    counters hang together; the GPU test compares the frame itself (tests/test_gpu_parity.py)."""
+    g = json.load(open(os.path.join(GOLDEN, "cfg2_full_digest.json")))
+    c = g["counters"]
+    assert c["paths"] == g["width"] * g["height"] * 121 and g["sample_count"] == 128
+    assert c["rays"] > c["paths"] and c["hits_shaded"] == 2 * c["shaded_vertices"] and c["texture_taps"] == 0
+    assert len(g["sha256_accum_then_ids"]) == 64 and len(g["sha256_rgba8"]) == 64

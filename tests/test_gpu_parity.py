@@ -4,6 +4,8 @@ float accumulators (sum of the clamped per-sample radiance + valid-sample count)
 primary-hit triangle ids, the work counters and the rgba8 image are all compared for
 equality, not tolerance, because both sides evaluate the same FMA-free expressions with
 the same transcendental definitions (include/pt_glsl_math.h)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -178,6 +180,15 @@ def test_cfg2_full_size_properties(renderer, oracle, monkeypatch):
     assert (accum[536:548].view(np.uint32) == o_accum[536:548].view(np.uint32)).all()
     assert (rgba[536:548] == o_rgba[536:548]).all()
     digest = hashlib.sha256(accum.tobytes() + ids.tobytes()).hexdigest()
+    # the WHOLE frame against the oracle: its digest of this frame was computed on the CPU (250.9 M paths, minutes)
+    # and committed (tests/golden/make_cfg2_digest.py)
+    import json
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg2_full_digest.json")))
+    assert (gold["width"], gold["height"], gold["sample_count"], gold["seed"]) == (1920, 1080, 128, 0x5EED0000)
+    assert digest == gold["sha256_accum_then_ids"]
+    assert hashlib.sha256(rgba.tobytes()).hexdigest() == gold["sha256_rgba8"]
+    for k in COUNTERS:
+        assert st[k] == gold["counters"][k], k
     rgba2, accum2, ids2, st2 = renderer.render_params(rp)  # idempotent
     assert hashlib.sha256(accum2.tobytes() + ids2.tobytes()).hexdigest() == digest
     # the wavefront pipeline at full size: queue striding (more entries than the shade grid), compaction on
