@@ -206,6 +206,7 @@ int ensure_state(pt_ctx* ctx, uint32_t slots, uint32_t lights, uint32_t pixels) 
   ALLOC(st.counters, PT_CNT_WORDS);
   st.stat_rows = slots / 64 * 2 + 16;  // >= the largest grid (64-thread blocks, rounded up to a multiple of 8)
   ALLOC(st.stats, static_cast<size_t>(PT_K_COUNT) * st.stat_rows * PT_ST_WORDS);
+  ALLOC(st.stat_totals, static_cast<size_t>(PT_K_COUNT) * PT_ST_WORDS);
   ALLOC(ctx->accum_out, pixels);
   ALLOC(ctx->primary_out, pixels);
   ALLOC(ctx->rgba8_out, pixels);
@@ -642,19 +643,14 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
     iter_total += iter;
   }
   const uint64_t iter = iter_total;
+  if (stats_out) ptd::launch_sum_stats(st, stream);
   PT_HIP(ctx, hipEventRecord(ctx->ev_stop, stream));
   PT_HIP(ctx, hipGetLastError());
   PT_HIP(ctx, hipStreamSynchronize(stream));
 
   if (stats_out) {
     unsigned long long h[PT_K_COUNT][PT_ST_WORDS] = {};
-    {
-      std::vector<unsigned long long> rows(static_cast<size_t>(PT_K_COUNT) * st.stat_rows * PT_ST_WORDS);
-      PT_HIP(ctx, hipMemcpy(rows.data(), st.stats, rows.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-      for (int k = 0; k < PT_K_COUNT; ++k)
-        for (size_t r = 0; r < st.stat_rows; ++r)
-          for (int w = 0; w < PT_ST_WORDS; ++w) h[k][w] += rows[(static_cast<size_t>(k) * st.stat_rows + r) * PT_ST_WORDS + w];
-    }
+    PT_HIP(ctx, hipMemcpy(&h[0][0], st.stat_totals, sizeof(h), hipMemcpyDeviceToHost));  // k_sum_stats ran at the end of the frame
     std::memset(stats_out, 0, sizeof(*stats_out));
     auto total = [&](int w) { return h[PT_K_INIT][w] + h[PT_K_EXTEND][w] + h[PT_K_SHADE][w] + h[PT_K_SHADOW][w]; };
     stats_out->paths = total(PT_ST_PATHS);

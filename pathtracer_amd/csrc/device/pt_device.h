@@ -77,6 +77,7 @@ struct pt_dev_state {
   uint32_t slot_stride;
   uint32_t* counters;
   unsigned long long* stats;  // [kernel][stat_rows][PT_ST_WORDS]: one row per block index, no atomics
+  unsigned long long* stat_totals;  // [kernel][PT_ST_WORDS]: column sums of `stats`, formed by k_sum_stats after the frame
   uint32_t stat_rows;         // >= the largest grid (slot_count / 64 + 1)
 };
 
@@ -92,6 +93,7 @@ void launch_shadow(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_s
 void launch_paths(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity, uint32_t cnt_in,
                   uint32_t cnt_out, uint32_t cnt_zero, uint32_t max_entries, uint32_t block, uint32_t max_blocks,
                   uint32_t max_vertices, uint32_t xcd_chunk, hipStream_t s);
+void launch_sum_stats(const pt_dev_state& st, hipStream_t s);
 void launch_finalize(const pt_dev_frame& f, const pt_dev_state& st, float4* accum_out, uint32_t* primary_out, hipStream_t s);
 void launch_resolve(const float4* accum, uint32_t pixel_count, uint32_t* rgba8, hipStream_t s);
 }  // namespace ptd

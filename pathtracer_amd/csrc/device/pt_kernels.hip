@@ -1324,6 +1324,25 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_paths(pt_dev_scene sc, pt_de
   flush_tally(walks, st, PT_K_SHADOW);
 }
 
+// Column sums of the per-block counter table: one workgroup per kernel slice, so the host reads
+// PT_K_COUNT x PT_ST_WORDS words instead of the whole table (16 MB at 1080p: ~1.5 ms of the frame's wall time).
+__global__ __launch_bounds__(256) void k_sum_stats(pt_dev_state st) {
+  __shared__ unsigned long long part[4][PT_ST_WORDS];
+  const unsigned long long* rows = st.stats + static_cast<size_t>(blockIdx.x) * st.stat_rows * PT_ST_WORDS;
+  unsigned long long acc[PT_ST_WORDS] = {};
+  for (uint32_t r = threadIdx.x; r < st.stat_rows; r += blockDim.x)
+    for (int w = 0; w < PT_ST_WORDS; ++w) acc[w] += rows[static_cast<size_t>(r) * PT_ST_WORDS + w];
+  for (int w = 0; w < PT_ST_WORDS; ++w) {
+    unsigned long long v = acc[w];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if (lane_id() == 0) part[wave_id()][w] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < PT_ST_WORDS)
+    st.stat_totals[blockIdx.x * PT_ST_WORDS + threadIdx.x] =
+        part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+}
+
 // slot order -> pixel order: accum_out = (sum R, sum G, sum B, valid samples)
 __global__ __launch_bounds__(256) void k_finalize(pt_dev_frame f, pt_dev_state st, float4* accum_out, uint32_t* primary_out) {
   const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1452,6 +1471,8 @@ void launch_paths(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_st
 #undef PT_LAUNCH_PATHS_LDS
 #undef PT_LAUNCH_PATHS
 }
+
+void launch_sum_stats(const pt_dev_state& st, hipStream_t s) { hipLaunchKernelGGL(k_sum_stats, dim3(PT_K_COUNT), dim3(256), 0, s, st); }
 
 void launch_finalize(const pt_dev_frame& f, const pt_dev_state& st, float4* accum_out, uint32_t* primary_out, hipStream_t s) {
   hipLaunchKernelGGL(k_finalize, dim3(blocks_for(f.slot_count, 256)), dim3(256), 0, s, f, st, accum_out, primary_out);
