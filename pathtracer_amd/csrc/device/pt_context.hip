@@ -55,6 +55,7 @@ struct pt_ctx {
   uint32_t band_slots = 0;          // 0 = whole frame in one band
   uint32_t trace_blocks = 0;        // grid cap of k_extend (persistent workgroups striding the queue)
   uint32_t shade_blocks = 0;        // grid cap of k_shade
+  bool log_launches = false;        // PT_LOG_LAUNCHES: print the polled live-slot count of every launch to stderr
   int pipeline = 0;                 // 0: path kernel (k_paths); 1: wavefront (k_extend + k_shade [+ k_shadow]); PT_PIPELINE=paths|wavefront
   uint32_t paths_vertices = 32;     // path vertices a slot advances per k_paths launch (PT_PATHS_VERTICES)
   uint32_t paths_blocks = 0xFFFFFFFFu; // grid cap of k_paths (PT_PATHS_BLOCKS)
@@ -264,6 +265,7 @@ extern "C" pt_ctx* pt_create(int device) {
   if (const char* e = std::getenv("PT_LDS_SCENE_BYTES")) ctx->lds_scene_bytes = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   if (ctx->trace_blocks == 0) ctx->trace_blocks = 2048;
   if (ctx->lds_scene_bytes > 32768) ctx->lds_scene_bytes = 32768;
+  ctx->log_launches = std::getenv("PT_LOG_LAUNCHES") != nullptr;
   if (const char* e = std::getenv("PT_PIPELINE")) ctx->pipeline = (std::string(e) == "wavefront") ? 1 : 0;
   if (const char* e = std::getenv("PT_PATHS_VERTICES")) ctx->paths_vertices = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   if (ctx->paths_vertices == 0) ctx->paths_vertices = 1;
@@ -584,6 +586,7 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
       if (have_prev) {
         PT_HIP(ctx, hipEventSynchronize(ctx->poll_events[poll ^ 1]));
         const uint32_t live = ctx->host_counts[poll ^ 1];
+        if (ctx->log_launches) std::fprintf(stderr, "[pt] band %u: %u slots live after the launch before last\n", base, live);
         if (live == 0) drained = true;
         else if (live < bound) bound = live;
       }
