@@ -105,7 +105,11 @@ void ClearNode(pt_bvh_node& nd) {
 class Pool {
  public:
   explicit Pool(unsigned size) : size_(size) {
-    for (unsigned t = 1; t < size_; ++t) threads_.emplace_back([this, t] { Loop(t); });
+    try {
+      for (unsigned t = 1; t < size_; ++t) threads_.emplace_back([this, t] { Loop(t); });
+    } catch (...) {  // the system refuses more threads: go on with the ones that started
+      size_ = static_cast<unsigned>(threads_.size()) + 1;
+    }
   }
   ~Pool() {
     {
