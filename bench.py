@@ -2,14 +2,23 @@
 """bench.py — the hot path (main.comp's work) on N MI355X, one process per GPU.
 
 A "step" is one full render of the workload (one pass of the hot path over one frame of
-synthetic input, scene already resident in HBM).  Default workload = BASELINE.json
+synthetic input, scene already resident in HBM).  Headline workload = BASELINE.json
 configs[1]: the generated Cornell box with an area light, 1920x1080, sample_count 128
-(121 effective strata, main.comp:596) on one GPU.
+(121 effective strata, main.comp:596).
 
-N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): weak scaling — every
-rank renders the same frame with all 121 strata from its own decorrelated seed, the float4
-accumulators (sum RGB + valid-sample count) are sum-reduced to rank 0 over xGMI (the
-path's one real exchange step) and rank 0 resolves the N x 121 spp image.
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL):
+  --split replicate (default, weak scaling): every rank renders the same frame with all its
+      strata from its own decorrelated seed;
+  --split strata (strong scaling of one frame, the split BASELINE configs[3]/[4] are defined
+      on): rank r renders strata [r n^2/N, (r+1) n^2/N) of every pixel.
+Either way the float4 accumulators (sum RGB + valid-sample count) are sum-reduced to rank 0
+over xGMI — the path's one exchange step, SURVEY.md §8e — and rank 0 resolves the image.
+Render, reduce and resolve are ordered on ONE explicit (non-default) stream per rank.
+
+At N = 1 the same command also measures the other single-GPU configs of BASELINE.json
+(`--configs`, default cfg1 cube512, cfg3 atrium1080, cfg4's one-GPU frame rocks1080) and
+reports them in the `configs` array of the same JSON line, each with counters, roofline and
+a bounded CPU-oracle sample that is ALSO compared bit for bit with the GPU frame.
 
 Prints ONE JSON line on rank 0.
 """
@@ -17,6 +26,7 @@ from __future__ import annotations
 
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import sys
@@ -26,7 +36,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-VALU_PEAK_TFLOPS = 157.3       # packed-FMA fp32 vector peak; plain v_fma_f32 is half (78.6)
+VALU_PEAK_TFLOPS = 157.3       # packed-FMA fp32 vector peak (256 CUs x 128 lanes x 2 flop x 2.4 GHz)
+VALU_NO_FMA_TFLOPS = 78.6      # what an FMA-free instruction stream (the bit-exact arithmetic contract) can reach at best
+LDS_PEAK_GBS = 150000.0        # ds_read_b128 aggregate, every CU streaming (MI355X_MICROARCH.md §LDS)
 
 WORKLOADS = {
     # name: (scene factory name, kwargs, width, height, sample_count, description)
@@ -37,12 +49,105 @@ WORKLOADS = {
     "atrium1080": ("atrium_scene", {"detail": 16, "tex_size": 1024}, 1920, 1080, 256,
                    "cfg3: generated Sponza-class textured PBR atrium (~253k triangles, 44 1024^2 textures), 1920x1080, 256 spp"),
     "rocks1080": ("rocks_scene", {"n_tris": 5_000_000}, 1920, 1080, 512,
-                  "cfg4: generated ~5M-triangle rock clusters (deep BVH), 1920x1080, 512 spp (484 effective)"),
+                  "cfg4: generated ~5M-triangle rock clusters (deep BVH), 1920x1080, 512 spp (484 effective); one GPU's frame"),
+    "cornell4k": ("cornell_scene", {}, 3840, 2160, 4096,
+                  "cfg5: Cornell box + area light, 3840x2160, 4096 spp (64x64 strata)"),
+    "cornell_tiny": ("cornell_scene", {}, 96, 54, 16, "test-sized Cornell box (tests/test_bench_script.py); not a bench line"),
 }
-WORKLOADS["cornell4k"] = ("cornell_scene", {}, 3840, 2160, 4096,
-                          "cfg5: Cornell box + area light, 3840x2160, 4096 spp (64x64 strata), one GPU's share when N > 1 is the full frame (weak scaling)")
 BG = {"atrium1080": (0.5, 0.7, 1.0), "rocks1080": (0.5, 0.7, 1.0), "soup1080": (0.5, 0.7, 1.0)}  # sky; others: README default
+EXTRA_DEFAULT = "cube512,atrium1080,rocks1080"
+EXTRA_STEPS = {"cube512": 20, "atrium1080": 2, "rocks1080": 2}
+SEED = 0x5EED0000
+COUNTERS = ("paths", "rays", "rays_closest", "rays_shadow_walked", "rays_shadow_shortcut", "node_visits", "tri_tests",
+            "hits_shaded", "texture_taps", "shaded_vertices", "nan_samples")
 
+T_START = time.perf_counter()
+
+
+def progress(msg: str) -> None:
+    """One line on stderr per phase: long workloads (5 M triangles) must not look hung."""
+    print(f"[bench +{time.perf_counter() - T_START:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+# --------------------------------------------------------------------------- backends
+
+class HipBackend:
+    """The product path: libpathtracer_amd.so through the C ABI, device buffers and the collective from torch.
+    Render, reduce and resolve all run on `self.stream`, an explicit non-default stream (the library's NULL stream
+    is its own non-blocking stream, unordered against a collective: include/pathtracer_amd.h)."""
+    dist_backend = "nccl"
+
+    def __init__(self, local_rank: int):
+        import torch
+        from pathtracer_amd.renderer import Renderer
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+        self.torch = torch
+        torch.cuda.set_device(local_rank)
+        self.dev = torch.device("cuda", local_rank)
+        self.r = Renderer(local_rank)
+        self.lib = self.r.lib
+        self.stream = torch.cuda.Stream(self.dev)
+        self.tensor_device = self.dev
+        self.reduce_events = []
+
+    def pack(self, scene):
+        return self.r.pack(scene)
+
+    def upload(self, packed):
+        self.r.upload(packed)
+
+    def alloc(self, pixels: int):
+        t = self.torch
+        self.pixels = pixels
+        self.accum = t.empty(pixels * 4, dtype=t.float32, device=self.dev)
+        self.ids = t.empty(pixels, dtype=t.int32, device=self.dev)
+        self.rgba = t.empty(pixels, dtype=t.int32, device=self.dev)
+
+    def render(self, rp, stats, want_ids: bool = False):
+        from pathtracer_amd import abi  # noqa: F401
+        with self.torch.cuda.stream(self.stream):
+            rc = self.lib.pt_render_accum_device(self.r.ctx, C.byref(rp), C.c_void_p(self.accum.data_ptr()),
+                                                 C.c_void_p(self.ids.data_ptr()) if want_ids else None,
+                                                 C.c_void_p(self.stream.cuda_stream), C.byref(stats) if stats is not None else None)
+        self.r._check(rc, "pt_render_accum_device")
+
+    def reduce(self, dist):
+        t = self.torch
+        with t.cuda.stream(self.stream):
+            e0, e1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
+            e0.record(self.stream)
+            dist.reduce(self.accum, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI: 16 B/pixel
+            e1.record(self.stream)
+            self.reduce_events.append((e0, e1))
+
+    def reduce_ms(self) -> float:
+        ms = sum(a.elapsed_time(b) for a, b in self.reduce_events)
+        self.reduce_events = []
+        return ms
+
+    def resolve(self):
+        with self.torch.cuda.stream(self.stream):
+            rc = self.lib.pt_resolve_device(self.r.ctx, C.c_void_p(self.accum.data_ptr()), C.c_uint32(self.pixels),
+                                            C.c_void_p(self.rgba.data_ptr()), C.c_void_p(self.stream.cuda_stream))
+        self.r._check(rc, "pt_resolve_device")
+
+    def sync(self):
+        self.stream.synchronize()
+        self.torch.cuda.synchronize(self.dev)
+
+    def host_frame(self):
+        """(accum float32 [H*W,4], ids uint32 [H*W], rgba uint8 [H*W,4]) of the last render, on the host."""
+        import numpy as np
+        self.sync()
+        return (self.accum.cpu().numpy().reshape(-1, 4), self.ids.cpu().numpy().view(np.uint32),
+                self.rgba.cpu().numpy().view(np.uint8).reshape(-1, 4))
+
+    def close(self):
+        self.r.close()
+
+
+# --------------------------------------------------------------------------- rooflines
 
 def kernel_roofline(name: str, ks: dict, verts: int) -> dict:
     """Algorithmic bytes/flops of one kernel over its measured device time."""
@@ -54,69 +159,249 @@ def kernel_roofline(name: str, ks: dict, verts: int) -> dict:
     gbs = bytes_total / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
     tfs = flops_total / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     return {
-        "kernel": "k_" + name, "launches": ks["launches"], "avg_launch_us": 1e3 * ms / launches,
+        "kernel": "k_" + name, "launches": ks["launches"], "avg_launch_us": 1e3 * ms / launches, "ms": ms,
         "bytes_per_launch": bytes_total / launches, "flops_per_launch": flops_total / launches,
-        "hbm": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None},
-        "valu": {"bound": "valu", "achieved": tfs, "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfs / VALU_PEAK_TFLOPS},
+        "algorithmic_gbs": gbs, "algorithmic_tflops": tfs,
     }
 
 
-def cpu_baseline(packed, rp, seconds_hint: float = 15.0) -> dict:
-    """The CPU oracle (a port of main.comp, oracle/pt_oracle.c) timed on the host cores on a
-    bounded band of rows of the same workload. Reported beside the GPU number; never the target."""
+def roofline_of(sd: dict, scene_in_lds: bool, workload: str, scene_bytes: int, modified: bool) -> tuple[dict, dict]:
+    """`roofline` object of the dominant kernel of one profiled step (stats dict `sd`), plus the per-kernel table."""
+    work = ("rays", "node_visits", "tri_tests", "hits_shaded", "texture_taps")
+    if sd["path_kernel"]["launches"] and not sd["extend"]["launches"]:
+        # path pipeline: k_paths does the extend, shade and shadow-walk work of every vertex in one launch
+        pk = dict(sd["path_kernel"])
+        for k in work:
+            pk[k] = sd["extend"][k] + sd["shade"][k] + sd["shadow"][k]
+        sd["paths"] = pk
+        names = ("paths",)
+    else:
+        if sd["shadow"]["launches"] == 0:  # the shadow walks run inside k_shade: their traversal work belongs to it
+            for k in work:
+                sd["shade"][k] += sd["shadow"][k]
+        names = ("extend", "shade", "shadow")
+    kernels = {k: kernel_roofline(k, sd[k], sd["shaded_vertices"]) for k in names if sd[k]["launches"]}
+    dom = kernels[max(kernels, key=lambda k: sd[k]["ms"])]
+    traffic = traffic_source = None
+    traffic_file = os.path.join(ROOT, "profiles", f"traffic_{workload}.json")
+    if os.path.exists(traffic_file) and not modified:
+        # HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same workload (scripts/pmc_passes.sh)
+        tk = json.load(open(traffic_file)).get("kernels", {}).get(dom["kernel"])
+        if tk:
+            traffic, traffic_source = tk["bytes_per_launch"], os.path.relpath(traffic_file, ROOT)
+    common = {"kernel": dom["kernel"], "launches": dom["launches"], "avg_launch_us": dom["avg_launch_us"],
+              "bytes_per_launch": dom["bytes_per_launch"], "flops_per_launch": dom["flops_per_launch"],
+              "traffic": traffic, "traffic_source": traffic_source, "timed_step_ms": sd["render_ms"]}
+    valu = {"achieved": dom["algorithmic_tflops"], "peak": VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": dom["algorithmic_tflops"] / VALU_PEAK_TFLOPS,
+            "frac_of_no_fma_peak": dom["algorithmic_tflops"] / VALU_NO_FMA_TFLOPS,
+            "note": "algorithmic flops 44/node visit + 55/triangle test + 400/shaded vertex (SURVEY.md 8d) over the packed-FMA fp32 "
+                    "vector peak; the bit-exact contract forms no FMA, so 78.6 TFLOP/s is its ceiling"}
+    if scene_in_lds:
+        # The scene is staged in every workgroup's LDS: the algorithmic bytes are LDS reads, HBM sees only `traffic`
+        # (path state in and out per launch). What bounds the kernel is VALU issue, so that is the roofline reported.
+        roof = {"bound": "valu", **valu, **common, "served_from": "lds",
+                "lds_algorithmic_gbs": dom["algorithmic_gbs"], "lds_frac_of_read_peak": dom["algorithmic_gbs"] / LDS_PEAK_GBS}
+        if traffic is not None:
+            roof["hbm_traffic_gbs"] = traffic / (dom["avg_launch_us"] * 1e-6) / 1e9
+            roof["hbm_traffic_frac"] = roof["hbm_traffic_gbs"] / HBM_PEAK_GBS
+    else:
+        frac = dom["algorithmic_gbs"] / HBM_PEAK_GBS
+        roof = {"bound": "hbm", "achieved": dom["algorithmic_gbs"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": frac, **common,
+                "served_from": "l2/infinity-cache/hbm", "valu": valu}
+        # the measured ceiling of dependent random 64-byte gathers on this GPU (scripts/micro/gather64.hip:
+        # 11.1 TB/s within one XCD's L2, 4.4 TB/s at 32 MiB, 3.55 TB/s from 128 MiB up)
+        ceiling = 11100.0 if scene_bytes <= (4 << 20) else (4400.0 if scene_bytes <= (48 << 20) else 3550.0)
+        roof["random_gather_ceiling_gbs"] = ceiling
+        roof["frac_of_gather_ceiling"] = dom["algorithmic_gbs"] / ceiling
+    return roof, kernels
+
+
+# --------------------------------------------------------------------------- CPU baseline (the oracle, as checker and yardstick)
+
+def cpu_baseline(packed, rp, gpu_accum, gpu_ids, seconds_hint: float) -> dict:
+    """The CPU oracle (a port of main.comp, oracle/pt_oracle.c) timed on the host cores on a bounded band of rows of
+    the same frame, and that band compared bit for bit with the GPU's frame. Reported beside the GPU number; never
+    the target. This leg is the only place bench.py touches oracle/."""
+    import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     lib = oracle_lib.load()
     cores = min(16, os.cpu_count() or 1)
-    h = rp.pc.resolution_y
-    # warm up (library load, thread start), calibrate on 4 rows, then size the band for ~seconds_hint
+    w, h = rp.pc.resolution_x, rp.pc.resolution_y
     mid = h // 2
     t0 = time.perf_counter()
-    oracle_lib.render(lib, packed, rp, threads=cores, rows=(mid, min(mid + 1, h)), want_ids=False)
-    first = time.perf_counter() - t0
-    cal = 1 if first > 2.0 else min(4, h)  # heavy workloads (hundreds of spp on millions of triangles): one row is sample enough
-    t0 = time.perf_counter()
-    oracle_lib.render(lib, packed, rp, threads=cores, rows=(mid, min(mid + cal, h)), want_ids=False)
+    oracle_lib.render(lib, packed, rp, threads=cores, rows=(mid, min(mid + 1, h)), want_ids=False)  # warm-up + calibration
     dt = max(time.perf_counter() - t0, 1e-6)
-    progress(f"oracle: {cal} row(s) in {dt:.1f} s")
-    rows = int(max(cal, min(h, cal * seconds_hint / dt)))
+    rows = int(max(1, min(h, seconds_hint / dt)))
     y0 = max(0, mid - rows // 2)
     y1 = min(h, y0 + rows)
     t0 = time.perf_counter()
-    _, _, _, st = oracle_lib.render(lib, packed, rp, threads=cores, rows=(y0, y1), want_ids=False)
+    _, o_accum, o_ids, st = oracle_lib.render(lib, packed, rp, threads=cores, rows=(y0, y1), want_ids=True)
     dt = time.perf_counter() - t0
-    return {
+    out = {
         "value": st["rays"] / dt / 1e6, "unit": "Mrays/s", "mpaths_per_s": st["paths"] / dt / 1e6, "cores": cores,
         "kind": "port", "seconds": dt,
         "sample": f"rows {y0}..{y1} of {h} of the same frame ({st['paths']} paths, {st['rays']} rays), oracle/pt_oracle.c, {cores} threads",
     }
+    if gpu_accum is not None:
+        ga = gpu_accum.reshape(h, w, 4)[y0:y1].view(np.uint32)
+        gi = gpu_ids.reshape(h, w)[y0:y1]
+        out["gpu_band_bit_exact"] = bool((ga == o_accum[y0:y1].view(np.uint32)).all() and (gi == o_ids[y0:y1]).all())
+    return out
 
 
-T_START = time.perf_counter()
+# --------------------------------------------------------------------------- one workload
+
+def run_workload(be, name: str, steps: int, warmup: int, world: int, rank: int, split: str, spp_override: int,
+                 kernel_timing: bool, baseline_seconds: float, dist) -> dict | None:
+    """Render `name` steps times on every rank; returns rank 0's result dict (None elsewhere)."""
+    import numpy as np
+    import torch
+    from pathtracer_amd import abi, scenes
+    from pathtracer_amd.distributed import rank_seed
+
+    factory, kwargs, width, height, spp, desc = WORKLOADS[name]
+    if spp_override:
+        spp = spp_override
+    progress(f"{name}: generating the scene")
+    scene = getattr(scenes, factory)(**kwargs)
+    progress(f"{name}: {len(scene.triangles)} triangles; building the BVH")
+    t0 = time.perf_counter()
+    packed = be.pack(scene)
+    build_s = time.perf_counter() - t0
+    progress(f"{name}: {len(packed.nodes)} nodes, depth {packed.bvh_max_depth}; uploading")
+    be.upload(packed)
+    bg = BG.get(name, (0.239, 0.239, 0.239))
+    if split == "strata":
+        rp = packed.render_params(be.lib, width, height, spp, bg, SEED, rank, world)
+    else:  # replicate: one decorrelated stream family per rank, all strata
+        rp = packed.render_params(be.lib, width, height, spp, bg, rank_seed(SEED, rank))
+    pixels = width * height
+    be.alloc(pixels)
+    stats = abi.Stats()
+
+    def step(flags: int = 0, want_ids: bool = False, collective: bool = True):
+        rp.flags = flags
+        be.render(rp, stats, want_ids)
+        if world > 1 and collective:
+            be.reduce(dist)
+        if rank == 0:
+            be.resolve()
+
+    def fence():
+        be.sync()
+        if world > 1:
+            dist.barrier()
+        be.sync()
+
+    # The profiled step (HIP events around every launch on the launch stream) runs first: it is also a warm-up.
+    sd = None
+    if kernel_timing:
+        step(abi.FLAG_TIME_KERNELS)
+        be.sync()
+        sd = stats.as_dict()
+    for _ in range(warmup):
+        step()
+    fence()
+    if hasattr(be, "reduce_events"):
+        be.reduce_events = []
+    progress(f"{name}: timing {steps} step(s)")
+    t0 = time.perf_counter()
+    rays = paths = 0
+    render_ms = 0.0
+    for _ in range(steps):
+        step()
+        rays += stats.rays
+        paths += stats.paths
+        render_ms += stats.render_ms
+    fence()
+    elapsed = time.perf_counter() - t0
+    reduce_ms = be.reduce_ms() if world > 1 else 0.0
+    progress(f"{name}: {steps} timed step(s) in {elapsed:.2f} s")
+
+    tot = torch.tensor([elapsed, float(rays), float(paths)], dtype=torch.float64, device=be.tensor_device)
+    if world > 1:
+        mx = tot.clone()
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        elapsed = float(mx[0])
+    total_rays, total_paths = float(tot[1]), float(tot[2])
+
+    # Rank 0's own frame once more, un-reduced and with primary-hit ids: the frame the checks below look at.
+    verify = rank == 0 and (split == "replicate" or world == 1)
+    frame = None
+    if verify:
+        step(want_ids=True, collective=False)
+        frame = be.host_frame()
+    last = stats.as_dict()
+    if world > 1:
+        dist.barrier()
+    if rank != 0:
+        return None
+
+    eff = int(np.sqrt(np.float32(spp))) ** 2
+    out = {
+        "name": name, "workload": desc,
+        "value": total_rays / elapsed / 1e6, "unit": "Mrays/s", "mpaths_per_s": total_paths / elapsed / 1e6,
+        "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / max(steps, 1),
+        "device_ms_per_step": render_ms / max(steps, 1),
+        "config": {"workload": desc, "name": name, "resolution": [width, height], "sample_count": spp, "effective_spp": eff,
+                   "triangles": int(scene.triangles.shape[0]), "bvh_nodes": int(len(packed.nodes)),
+                   "bvh_depth": int(packed.bvh_max_depth), "host_bvh_build_s": build_s, "iterations": int(last["iterations"]),
+                   "rays_per_step_per_gpu": int(stats.rays), "paths_per_step_per_gpu": int(stats.paths)},
+        "counters": {k: int(last[k]) for k in COUNTERS},
+    }
+    if world > 1:
+        out["reduce_ms_per_step"] = reduce_ms / max(steps, 1)
+    if last["rays"]:
+        out["ray_mix"] = {"closest_hit": last["rays_closest"] / last["rays"], "shadow_walked": last["rays_shadow_walked"] / last["rays"],
+                          "shadow_shortcut_one_triangle_test": last["rays_shadow_shortcut"] / last["rays"]}
+    scene_bytes = 64 * (len(packed.nodes) // 2) + 48 * int(scene.triangles.shape[0])
+    if sd is not None:
+        out["roofline"], out["kernels"] = roofline_of(sd, bool(sd["scene_in_lds"]), name, scene_bytes, bool(spp_override))
+    if frame is not None:
+        accum, ids, rgba = frame
+        gold_file = os.path.join(ROOT, "tests", "golden", f"{name}_full_digest.json")
+        if name == "cornell1080":
+            gold_file = os.path.join(ROOT, "tests", "golden", "cfg2_full_digest.json")
+        if os.path.exists(gold_file) and not spp_override:
+            # the oracle's SHA-256 of this WHOLE frame, computed on the CPU and committed (tests/golden/make_*_digest.py)
+            gold = json.load(open(gold_file))
+            same_job = (gold["width"], gold["height"], gold["sample_count"], gold["seed"]) == (width, height, spp, rp.pc.seed)
+            ok = (same_job and hashlib.sha256(accum.tobytes() + ids.tobytes()).hexdigest() == gold["sha256_accum_then_ids"]
+                  and hashlib.sha256(rgba.tobytes()).hexdigest() == gold["sha256_rgba8"]
+                  and all(int(last[k]) == gold["counters"][k] for k in gold["counters"]))
+            out["frame_verified"] = bool(ok)
+            out["frame_verified_against"] = os.path.relpath(gold_file, ROOT)
+        valid = accum[:, 3]
+        out["frame_properties_ok"] = bool(np.isfinite(accum).all() and (accum[:, :3] >= 0).all() and (accum[:, :3] <= 10.0 * eff).all()
+                                          and (valid <= eff).all() and int((eff - valid).sum()) == last["nan_samples"]
+                                          and last["paths"] == pixels * eff and (rgba[:, 3] == 255).all())
+        if baseline_seconds > 0 and world == 1:
+            progress(f"{name}: timing the CPU oracle on a band of rows (and checking the GPU frame against it)")
+            rp.flags = 0
+            out["cpu_baseline"] = cpu_baseline(packed, rp, accum, ids, baseline_seconds)
+    return out
 
 
-def progress(msg: str) -> None:
-    """One line on stderr per phase: long workloads (5 M triangles) must not look hung."""
-    print(f"[bench +{time.perf_counter() - T_START:6.1f}s] {msg}", file=sys.stderr, flush=True)
-
-
-def main() -> None:
+def main(argv=None, backend_factory=None) -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="cornell1080", choices=sorted(WORKLOADS))
+    ap.add_argument("--split", default="replicate", choices=("replicate", "strata"),
+                    help="N > 1: every rank all strata from its own seed (weak scaling) or the strata divided over ranks (strong scaling)")
+    ap.add_argument("--configs", default=EXTRA_DEFAULT,
+                    help="N = 1: further single-GPU configs measured by the same command, comma separated ('none' to skip)")
     ap.add_argument("--spp", type=int, default=0, help="override sample_count (dev only; invalidates the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the extra profiled step that feeds `roofline`")
-    args = ap.parse_args()
+    ap.add_argument("--time-budget-s", type=float, default=420.0, help="extra configs are skipped once the run is this old")
+    args = ap.parse_args(argv)
 
-    import numpy as np
-    import torch
     import torch.distributed as dist
-
-    from pathtracer_amd import abi, scenes
-    from pathtracer_amd.renderer import Renderer
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -125,161 +410,47 @@ def main() -> None:
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
         sys.exit(2)
-    if not torch.cuda.is_available():
-        print("bench.py needs a GPU (the HIP path has no CPU fallback)", file=sys.stderr)
-        sys.exit(2)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    be = backend_factory(local_rank) if backend_factory else HipBackend(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        kw = {"device_id": be.dev} if be.dist_backend == "nccl" else {}
+        dist.init_process_group(be.dist_backend, rank=rank, world_size=world, **kw)
 
-    factory, kwargs, width, height, spp, desc = WORKLOADS[args.workload]
-    if args.spp:
-        spp = args.spp
-    progress(f"generating {args.workload}")
-    scene = getattr(scenes, factory)(**kwargs)
-    progress(f"{len(scene.triangles)} triangles; building the BVH")
-    r = Renderer(local_rank)
-    t0 = time.perf_counter()
-    packed = r.pack(scene)
-    build_s = time.perf_counter() - t0
-    progress(f"{len(packed.nodes)} nodes, depth {packed.bvh_max_depth}; uploading")
-    r.upload(packed)
-    progress("rendering")
-    from pathtracer_amd.distributed import rank_seed
-    seed = rank_seed(0x5EED0000, rank)  # "replicate" split: one decorrelated stream family per rank
-    rp = packed.render_params(r.lib, width, height, spp, BG.get(args.workload, (0.239, 0.239, 0.239)), seed)
-    pixels = width * height
-
-    accum = torch.empty(pixels * 4, dtype=torch.float32, device=dev)
-    rgba = torch.empty(pixels, dtype=torch.int32, device=dev)
-    stream = torch.cuda.current_stream(dev)
-    stats = abi.Stats()
-
-    def step(flags: int = 0):
-        rp.flags = flags
-        rc = r.lib.pt_render_accum_device(r.ctx, C.byref(rp), C.c_void_p(accum.data_ptr()), None,
-                                          C.c_void_p(stream.cuda_stream), C.byref(stats))
-        r._check(rc, "pt_render_accum_device")
-        if world > 1:
-            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI: 16 B/pixel
-        if rank == 0:
-            rc = r.lib.pt_resolve_device(r.ctx, C.c_void_p(accum.data_ptr()), C.c_uint32(pixels),
-                                         C.c_void_p(rgba.data_ptr()), C.c_void_p(stream.cuda_stream))
-            r._check(rc, "pt_resolve_device")
-
-    def fence():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    rays = paths = 0
-    render_ms = 0.0
-    for _ in range(args.steps):
-        step()
-        rays += stats.rays
-        paths += stats.paths
-        render_ms += stats.render_ms
-    fence()
-    elapsed = time.perf_counter() - t0
-    progress(f"{args.steps} timed steps in {elapsed:.2f} s")
-
-    tot = torch.tensor([elapsed, float(rays), float(paths)], dtype=torch.float64, device=dev)
-    if world > 1:
-        mx = tot.clone()
-        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        elapsed = float(mx[0])
-    total_rays, total_paths = float(tot[1]), float(tot[2])
-
-    roof = None
-    kernels = None
-    if not args.no_kernel_timing:
-        # per-kernel device time: HIP events around every launch on the launch stream
-        step(abi.FLAG_TIME_KERNELS)
-        torch.cuda.synchronize(dev)
-        sd = stats.as_dict()
-        work = ("rays", "node_visits", "tri_tests", "hits_shaded", "texture_taps")
-        if sd["path_kernel"]["launches"] and not sd["extend"]["launches"]:
-            # path pipeline: k_paths does the extend, shade and shadow-walk work of every vertex in one launch
-            pk = dict(sd["path_kernel"])
-            for k in work:
-                pk[k] = sd["extend"][k] + sd["shade"][k] + sd["shadow"][k]
-            sd["paths"] = pk
-            names = ("paths",)
-        else:
-            if sd["shadow"]["launches"] == 0:  # the shadow walks run inside k_shade: their traversal work belongs to it
-                for k in work:
-                    sd["shade"][k] += sd["shadow"][k]
-            names = ("extend", "shade", "shadow")
-        kernels = {k: kernel_roofline(k, sd[k], sd["shaded_vertices"]) for k in names if sd[k]["launches"]}
-        dominant = max(kernels, key=lambda k: sd[k]["ms"])
-        roof = dict(kernels[dominant]["hbm"])
-        roof["kernel"] = kernels[dominant]["kernel"]
-        roof["avg_launch_us"] = kernels[dominant]["avg_launch_us"]
-        roof["bytes_per_launch"] = kernels[dominant]["bytes_per_launch"]
-        roof["valu"] = kernels[dominant]["valu"]
-        roof["timed_step_ms"] = sd["render_ms"]
-        roof["kernel_ms"] = {k: sd[k]["ms"] for k in kernels}
-        if sd["path_kernel"]["launches"] and "paths" not in kernels:
-            roof["kernel_ms"]["paths"] = sd["path_kernel"]["ms"]
-        scene_bytes = 64 * (len(packed.nodes) // 2) + 48 * int(scene.triangles.shape[0])
-        if scene_bytes > 16384:
-            # scenes read from global memory: the measured ceiling of dependent random 64-byte gathers on this GPU
-            # (scripts/micro/gather64.hip: 11.1 TB/s within one XCD's L2, 4.4 TB/s at 32 MiB, 3.55 TB/s from 128 MiB up)
-            ceiling = 11100.0 if scene_bytes <= (4 << 20) else (4400.0 if scene_bytes <= (48 << 20) else 3550.0)
-            roof["random_gather_ceiling_gbs"] = ceiling
-            roof["frac_of_gather_ceiling"] = roof["achieved"] / ceiling
-        else:
-            # LDS-resident scene: the algorithmic bytes are read from each workgroup's LDS copy, not from HBM, so this
-            # fraction of the HBM peak can pass 1; what reaches memory is `traffic`, what binds is VALU issue (`valu`)
-            roof["served_from"] = "lds"
-        traffic_file = os.path.join(ROOT, "profiles", f"traffic_{args.workload}.json")
-        if os.path.exists(traffic_file) and not args.spp:
-            # HBM-side bytes per launch from the committed rocprofv3 --pmc passes of this same command (scripts/pmc_passes.sh)
-            tk = json.load(open(traffic_file)).get("kernels", {}).get(roof["kernel"])
-            if tk:
-                roof["traffic"] = tk["bytes_per_launch"]
-                roof["traffic_source"] = os.path.relpath(traffic_file, ROOT)
+    head = run_workload(be, args.workload, args.steps, args.warmup, world, rank, args.split, args.spp,
+                        not args.no_kernel_timing, 0.0 if args.no_cpu_baseline else 12.0, dist)
+    extras = []
+    if world == 1 and args.configs != "none":
+        for name in [c for c in args.configs.split(",") if c and c != args.workload]:
+            if time.perf_counter() - T_START > args.time_budget_s:
+                extras.append({"name": name, "skipped": f"run older than --time-budget-s {args.time_budget_s:.0f}"})
+                continue
+            extras.append(run_workload(be, name, EXTRA_STEPS.get(name, 2), 0, 1, 0, "replicate", 0, not args.no_kernel_timing,
+                                       0.0 if args.no_cpu_baseline else 4.0, dist))
 
     if rank == 0:
-        last = stats.as_dict()
+        cfg = dict(head["config"])
+        cfg["parallelism"] = (f"dp{world}, {args.split}: " +
+                              ("strata of every pixel divided over the GPUs" if args.split == "strata" else "full frame per GPU, own seed") +
+                              ", RCCL sum-reduce of float4 accumulators")
         out = {
-            "metric": "Mrays/s at 1080p (rays = BVH traversals: closest-hit + shadow-walk steps)",
-            "value": total_rays / elapsed / 1e6,
-            "unit": "Mrays/s",
-            "mpaths_per_s": total_paths / elapsed / 1e6,
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
-            "device_ms_per_step": render_ms / max(args.steps, 1),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": desc, "name": args.workload, "resolution": [width, height], "sample_count": spp,
-                       "effective_spp": int(np.sqrt(np.float32(spp))) ** 2, "triangles": int(scene.triangles.shape[0]),
-                       "bvh_nodes": int(len(packed.nodes)), "bvh_depth": int(packed.bvh_max_depth),
-                       "parallelism": f"dp{world}: full frame per GPU, own seed, RCCL sum-reduce of float4 accumulators",
-                       "rays_per_step_per_gpu": int(last["rays"]), "paths_per_step_per_gpu": int(last["paths"]),
-                       "iterations": int(last["iterations"]), "host_bvh_build_s": build_s},
-            "counters": {k: int(last[k]) for k in ("paths", "rays", "node_visits", "tri_tests", "hits_shaded", "texture_taps",
-                                                   "shaded_vertices", "nan_samples")},
+            "metric": "Mrays/s at 1080p (rays = ray_scene_intersect calls of the reference: closest-hit + shadow-walk steps)",
+            "value": head["value"], "unit": "Mrays/s", "mpaths_per_s": head["mpaths_per_s"],
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": head["ms_per_step"],
+            "device_ms_per_step": head["device_ms_per_step"],
+            "higher_is_better": True, "scaling": "strong" if (args.split == "strata" and world > 1) else "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic", "config": cfg,
         }
-        if roof:
-            out["roofline"] = roof
-            out["kernels"] = kernels
-        if not args.no_cpu_baseline and world == 1:
-            progress("timing the CPU oracle on a band of rows")
-            out["cpu_baseline"] = cpu_baseline(packed, rp)
+        for k in ("counters", "ray_mix", "reduce_ms_per_step", "roofline", "kernels", "frame_verified", "frame_verified_against",
+                  "frame_properties_ok", "cpu_baseline"):
+            if k in head:
+                out[k] = head[k]
+        if extras:
+            out["configs"] = extras
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    r.close()
+    be.close()
 
 
 if __name__ == "__main__":

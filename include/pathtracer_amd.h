@@ -223,6 +223,14 @@ typedef struct pt_stats {
   pt_kernel_stats shade;   /* shading, light sampling, regeneration, compaction (k_shade, k_paths) */
   pt_kernel_stats shadow;  /* the shadow walks (run inside k_shade / k_paths, or k_shadow): their traversal work */
   pt_kernel_stats path_kernel; /* k_paths: launches and device time only (its work is counted in the three slices above) */
+  /* the ray mix behind `rays` (rays = rays_closest + rays_shadow_walked + rays_shadow_shortcut) */
+  uint64_t rays_closest;         /* closest-hit traversals of path segments (main.comp:516)                    */
+  uint64_t rays_shadow_walked;   /* shadow-walk steps that traversed the tree (main.comp:306-332)              */
+  uint64_t rays_shadow_shortcut; /* all-opaque scenes: area-light samples decided by the one-triangle test of
+                                    the sampled emitter, without a tree walk (the reference traverses; the result
+                                    is provably the same). 0 from the CPU oracle's reference mode. */
+  uint64_t scene_in_lds;         /* 1: the scene was small enough to be staged whole in every workgroup's LDS
+                                    (its fetches are LDS reads, not HBM traffic: the render is VALU-bound)      */
 } pt_stats;
 
 #define PT_FLAG_TIME_KERNELS 1u /* bracket every kernel with HIP events (serialises; for profiling) */
@@ -262,9 +270,13 @@ PT_API int pt_render(pt_ctx* ctx, const pt_render_params* params,
 /* Multi-GPU halves of pt_render (no counterpart in the reference, which is single
  * device): render this rank's strata into a DEVICE accumulator (float4 per pixel,
  * overwritten), to be sum-reduced over ranks by the caller (RCCL), then resolved.
- * `stream` is a hipStream_t (NULL = the context's own stream). Both are asynchronous
- * with respect to the host only as far as the stream is; pt_render_accum_device
- * itself polls the device for completion of the wavefront loop before returning. */
+ * `stream` is a hipStream_t. NULL is NOT the legacy default stream: it selects the
+ * context's own stream, which is created non-blocking and is therefore unordered
+ * against stream 0 and against a collective's stream. A caller that puts a collective
+ * between the two calls must pass the (non-NULL) stream the collective is ordered on
+ * to both, or synchronise in between. pt_render_accum_device returns after the render
+ * loop has drained on `stream` (it polls the live-slot count); pt_resolve_device only
+ * enqueues. */
 PT_API int pt_render_accum_device(pt_ctx* ctx, const pt_render_params* params,
                                   float* accum_dev, uint32_t* primary_id_dev,
                                   void* stream, pt_stats* stats_out);

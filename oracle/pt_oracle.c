@@ -614,9 +614,11 @@ static float ray_scene_intersect_with_transparency(shctx* c, ray_t ray, isect_t*
       ray_triangle_intersect(c, &ray, target_tri, info);
       if (info->tri_idx != ORC_NO_HIT) {
         ++c->st.rays;
+        ++c->st.rays_shadow_shortcut;
         return 0.0f;
       }
     }
+    ++c->st.rays_shadow_walked;
     ray_scene_intersect_ex(c, &ray, info, 1);
     return info->tri_idx == ORC_NO_HIT ? 1.0f : 0.0f;
   }
@@ -624,6 +626,7 @@ static float ray_scene_intersect_with_transparency(shctx* c, ray_t ray, isect_t*
     ++step;
     info->t = ORC_INFINITY;
     info->tri_idx = ORC_NO_HIT;
+    ++c->st.rays_shadow_walked;
     ray_scene_intersect(c, &ray, info);
     if (info->tri_idx == ORC_NO_HIT) break;
 
@@ -836,6 +839,7 @@ static v3 trace(shctx* c, ray_t ray, uint32_t* first_hit) {
   while (light_steps < ORC_MAX_LIGHT_STEPS) {
     isect_t info;
     info.t = ORC_INFINITY; info.u = info.v = 0.0f; info.tri_idx = ORC_NO_HIT;
+    ++c->st.rays_closest;
     ray_scene_intersect(c, &ray, &info);
     if (first) {
       if (first_hit) *first_hit = info.tri_idx;
@@ -1062,6 +1066,9 @@ int orc_render_ex(const pt_scene_desc* scene, const pt_render_params* params, ui
     total.texture_taps += args[i].st.texture_taps;
     total.shaded_vertices += args[i].st.shaded_vertices;
     total.nan_samples += args[i].st.nan_samples;
+    total.rays_closest += args[i].st.rays_closest;
+    total.rays_shadow_walked += args[i].st.rays_shadow_walked;
+    total.rays_shadow_shortcut += args[i].st.rays_shadow_shortcut;
   }
   if (stats_out) *stats_out = total;
   return 0;

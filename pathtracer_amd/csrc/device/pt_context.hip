@@ -65,7 +65,7 @@ struct pt_ctx {
   bool split_shadow = true;         // scenes in global memory: shadow walks in their own kernel (PT_SPLIT_SHADOW=0 keeps them in k_shade)
   uint32_t tail_entries = 262144;   // queue length below which the rest of the frame runs in one k_tail launch (0 = never)
   uint32_t lds_scene_bytes = 16384; // scenes up to this size (pair records + triangle positions) are staged whole in LDS
-  uint32_t* host_counts = nullptr;  // pinned
+  uint32_t* host_counts = nullptr;  // pinned: [0..1] polled live-slot counts, from byte 64 on the work-counter totals
   hipEvent_t poll_events[2] = {nullptr, nullptr};
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   std::vector<hipEvent_t> kernel_events;
@@ -282,7 +282,8 @@ extern "C" pt_ctx* pt_create(int device) {
   if (const char* e = std::getenv("PT_BAND_SLOTS")) ctx->band_slots = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   bool ok = hipSetDevice(device) == hipSuccess &&
             hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
-            hipHostMalloc(reinterpret_cast<void**>(&ctx->host_counts), 64, hipHostMallocDefault) == hipSuccess &&
+            hipHostMalloc(reinterpret_cast<void**>(&ctx->host_counts), 64 + sizeof(unsigned long long) * PT_K_COUNT * PT_ST_WORDS,
+                          hipHostMallocDefault) == hipSuccess &&
             hipEventCreate(&ctx->poll_events[0]) == hipSuccess && hipEventCreate(&ctx->poll_events[1]) == hipSuccess &&
             hipEventCreate(&ctx->ev_start) == hipSuccess && hipEventCreate(&ctx->ev_stop) == hipSuccess;
   if (!ok) {
@@ -533,7 +534,8 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
                                              : 0u;
   if (256u * sc.stack_entries * 4u + scene_lds > 65536u) sc.scene_in_lds = 0;  // deep tree: the stack needs the LDS
   const uint32_t trace_block = (256u * sc.stack_entries * 4u <= 65536u) ? 256u : 64u;
-  const bool split = ctx->pipeline == 1 && ctx->split_shadow && !sc.scene_in_lds && n_lights != 0;
+  const int pipeline = ctx->pipeline;
+  const bool split = pipeline == 1 && ctx->split_shadow && !sc.scene_in_lds && n_lights != 0;
   int rc = ensure_state(ctx, band_slots, split ? n_lights : 0u, pixels);
   if (rc != PT_OK) return rc;
   const pt_dev_state& st = ctx->state;
@@ -595,7 +597,7 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
       return PT_OK;
     };
 
-    if (ctx->pipeline == 0) {
+    if (pipeline == 0) {
       // ---- path pipeline: one k_paths launch advances every queued slot by up to paths_vertices vertices
       uint64_t vertices = 0;
       for (uint32_t k = 0; !drained && vertices < max_iters; ++k, vertices += ctx->paths_vertices) {
@@ -653,10 +655,18 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
 
   if (stats_out) {
     unsigned long long h[PT_K_COUNT][PT_ST_WORDS] = {};
-    PT_HIP(ctx, hipMemcpy(&h[0][0], st.stat_totals, sizeof(h), hipMemcpyDeviceToHost));  // k_sum_stats ran at the end of the frame
+    // k_sum_stats ran at the end of the frame; read its 256 bytes through the context's pinned words (no staging allocation)
+    unsigned long long* pinned = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(ctx->host_counts) + 64);
+    PT_HIP(ctx, hipMemcpyAsync(pinned, st.stat_totals, sizeof(h), hipMemcpyDeviceToHost, stream));
+    PT_HIP(ctx, hipStreamSynchronize(stream));
+    std::memcpy(&h[0][0], pinned, sizeof(h));
     std::memset(stats_out, 0, sizeof(*stats_out));
     auto total = [&](int w) { return h[PT_K_INIT][w] + h[PT_K_EXTEND][w] + h[PT_K_SHADE][w] + h[PT_K_SHADOW][w]; };
-    stats_out->paths = total(PT_ST_PATHS);
+    // (the shadow slice's PATHS word counts the shortcut-decided shadow rays, not paths)
+    stats_out->paths = h[PT_K_INIT][PT_ST_PATHS] + h[PT_K_EXTEND][PT_ST_PATHS] + h[PT_K_SHADE][PT_ST_PATHS];
+    stats_out->rays_closest = h[PT_K_EXTEND][PT_ST_RAYS];
+    stats_out->rays_shadow_shortcut = h[PT_K_SHADOW][PT_ST_PATHS];
+    stats_out->rays_shadow_walked = h[PT_K_SHADE][PT_ST_RAYS] + h[PT_K_SHADOW][PT_ST_RAYS] - h[PT_K_SHADOW][PT_ST_PATHS];
     stats_out->rays = total(PT_ST_RAYS);
     stats_out->node_visits = total(PT_ST_VISITS);
     stats_out->tri_tests = total(PT_ST_TESTS);
@@ -665,6 +675,7 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
     stats_out->shaded_vertices = total(PT_ST_VERTS);
     stats_out->nan_samples = total(PT_ST_NANS);
     stats_out->iterations = iter;
+    stats_out->scene_in_lds = sc.scene_in_lds;
     pt_kernel_stats* per[PT_K_COUNT + 1] = {nullptr, &stats_out->extend, &stats_out->shade, &stats_out->shadow, &stats_out->path_kernel};
     stats_out->path_kernel.launches = launches[PT_K_PATHS];
     for (int k = PT_K_EXTEND; k < PT_K_COUNT; ++k) {

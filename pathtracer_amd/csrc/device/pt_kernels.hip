@@ -967,6 +967,7 @@ __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const Shade
         ray_triangle<IN_LDS>(tr, shadow_origin, l, etri, sh);
         if (sh.tri != kNoHit) {
           ++walks.rays;
+          ++walks.paths;  // in the shadow slice this word counts the rays decided by the shortcut (pt_stats.rays_shadow_shortcut)
           continue;
         }
       }
@@ -1219,6 +1220,7 @@ __global__ __launch_bounds__(256, ALL_OPAQUE ? PT_SHADOW_MIN_WAVES_OPAQUE : PT_S
           ray_triangle<false>(tr, origin, l, fbits(r3.y), sh);
           if (sh.tri != kNoHit) {
             ++walks.rays;
+            ++walks.paths;  // shortcut count (see shade_vertex)
             continue;
           }
         }

@@ -38,15 +38,31 @@ def strata_range(total: int, rank: int, world: int) -> tuple[int, int]:
     return (rank * total) // world, ((rank + 1) * total) // world
 
 
+_STREAMS: dict = {}
+
+
+def render_stream(device):
+    """The ONE explicit, non-default stream per device on which render, reduce and resolve are ordered.
+    The library's NULL stream is its own non-blocking stream (include/pathtracer_amd.h), unordered against
+    torch's streams and against the collective; torch's default stream has handle 0 == NULL, so it must
+    never be the one passed."""
+    key = (device.type, device.index)
+    if key not in _STREAMS:
+        _STREAMS[key] = torch.cuda.Stream(device)
+    return _STREAMS[key]
+
+
 def hip_backend(renderer) -> Callable:
     """render_accum(rp) -> float32 CUDA tensor [H*W*4] using the HIP path on renderer's GPU."""
     def render(rp: abi.RenderParams) -> torch.Tensor:
         dev = torch.device("cuda", torch.cuda.current_device())
         pixels = rp.pc.resolution_x * rp.pc.resolution_y
-        accum = torch.empty(pixels * 4, dtype=torch.float32, device=dev)
-        stream = torch.cuda.current_stream(dev)
-        rc = renderer.lib.pt_render_accum_device(renderer.ctx, C.byref(rp), C.c_void_p(accum.data_ptr()), None,
-                                                 C.c_void_p(stream.cuda_stream), None)
+        stream = render_stream(dev)
+        with torch.cuda.stream(stream):  # allocation, render (and the caller's reduce, see hip_reduce) on this stream
+            accum = torch.empty(pixels * 4, dtype=torch.float32, device=dev)
+            assert stream.cuda_stream != 0
+            rc = renderer.lib.pt_render_accum_device(renderer.ctx, C.byref(rp), C.c_void_p(accum.data_ptr()), None,
+                                                     C.c_void_p(stream.cuda_stream), None)
         renderer._check(rc, "pt_render_accum_device")
         return accum
     return render
@@ -55,14 +71,25 @@ def hip_backend(renderer) -> Callable:
 def hip_resolve(renderer) -> Callable:
     def resolve(accum: torch.Tensor) -> np.ndarray:
         pixels = accum.numel() // 4
-        rgba = torch.empty(pixels, dtype=torch.int32, device=accum.device)
-        stream = torch.cuda.current_stream(accum.device)
-        rc = renderer.lib.pt_resolve_device(renderer.ctx, C.c_void_p(accum.data_ptr()), C.c_uint32(pixels),
-                                            C.c_void_p(rgba.data_ptr()), C.c_void_p(stream.cuda_stream))
+        stream = render_stream(accum.device)
+        with torch.cuda.stream(stream):
+            rgba = torch.empty(pixels, dtype=torch.int32, device=accum.device)
+            rc = renderer.lib.pt_resolve_device(renderer.ctx, C.c_void_p(accum.data_ptr()), C.c_uint32(pixels),
+                                                C.c_void_p(rgba.data_ptr()), C.c_void_p(stream.cuda_stream))
         renderer._check(rc, "pt_resolve_device")
-        torch.cuda.synchronize(accum.device)
+        stream.synchronize()
         return rgba.cpu().numpy().view(np.uint8).reshape(-1, 4)
     return resolve
+
+
+def reduce_to_rank0(accum: torch.Tensor) -> None:
+    """The path's one exchange step. For a CUDA tensor the collective is issued with the render stream current, so
+    RCCL orders it after the render and the resolve (same stream) after it."""
+    if accum.is_cuda:
+        with torch.cuda.stream(render_stream(accum.device)):
+            dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
+    else:
+        dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)
 
 
 def render_distributed(make_params: Callable[[int, int, int], abi.RenderParams], render_accum: Callable,
@@ -82,7 +109,7 @@ def render_distributed(make_params: Callable[[int, int, int], abi.RenderParams],
         raise ValueError(mode)
     accum = render_accum(rp)
     if world > 1:
-        dist.reduce(accum, dst=0, op=dist.ReduceOp.SUM)  # the path's one exchange step
+        reduce_to_rank0(accum)
     if rank != 0:
         return None, None
     return resolve(accum), accum

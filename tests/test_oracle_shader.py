@@ -114,7 +114,11 @@ def test_rank_split_covers_every_stratum_once(oracle):
     for r in range(3):
         _, accum, _, st = render(oracle, s, 16, 12, 16, seed=5, rank=r, num_ranks=3)
         total += st["paths"]
-        assert (accum[..., 3] == [5, 5, 6][r] if False else True)
+        n = [5, 5, 6][r]  # strata_range(16, r, 3): [0,5) [5,10) [10,16)
+        assert st["paths"] == 16 * 12 * n
+        # valid-sample count per pixel = the rank's strata minus the samples its NaN filter dropped
+        assert (accum[..., 3] <= n).all() and int((n - accum[..., 3]).sum()) == st["nan_samples"]
+        assert (accum[..., 3] == n).mean() > 0.99
     assert total == 16 * 12 * 16
 
 
