@@ -4,6 +4,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PT_LIB_PATH", os.path.join(_HERE, "libpathtracer_amd.so"))  # PT_LIB_PATH: experiment builds
@@ -17,6 +18,16 @@ def load() -> C.CDLL:
             raise RuntimeError(
                 f"{LIB_PATH} is missing: build it with `python -m pathtracer_amd.build` "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        # PyTorch's ROCm wheels bundle their own libamdhip64; this library links the system one. Whichever is loaded
+        # first serves both (same SONAME), but with the system runtime first torch then finds "No HIP GPUs". Callers
+        # that use torch for device buffers / torch.distributed next to this library (bench.py, distributed.py, the
+        # tests) therefore get torch's runtime loaded first, in whatever order they import things. Without torch
+        # (the C++ CLI, plain ctypes users) nothing changes.
+        if "torch" not in sys.modules and not os.environ.get("PT_NO_TORCH_PRELOAD"):
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         lib = C.CDLL(LIB_PATH)
         lib.pt_create.restype = C.c_void_p
         lib.pt_create.argtypes = [C.c_int]
