@@ -280,6 +280,24 @@ PT_API int pt_render(pt_ctx* ctx, const pt_render_params* params,
 PT_API int pt_render_accum_device(pt_ctx* ctx, const pt_render_params* params,
                                   float* accum_dev, uint32_t* primary_id_dev,
                                   void* stream, pt_stats* stats_out);
+/* pt_render_accum_device for callers that cannot allocate device memory (code under HIP
+ * graph capture, tight serving loops, harnesses that forbid hipMalloc). NO COUNTERPART IN
+ * THE REFERENCE. Same arguments, same results bit for bit, but the frame's working set
+ * (per-slot path state, slot queues, queue counters, work-counter table) lives in a fixed
+ * file-scope device array of the library (~26 MiB per GPU, held until the process ends)
+ * instead of hipMalloc'd buffers, and nothing is allocated or freed on the way (no
+ * hipMalloc / hipFree / hipEventCreate; the scene must already be uploaded).
+ * Limit: the frame may have at most PT_NOALLOC_MAX_SLOTS pixel slots, a slot being one
+ * pixel of the 8x8-tile grid, i.e. ceil(W/8)*ceil(H/8)*64 <= 262144 (512x512, BASELINE
+ * configs[0]); larger frames fail with PT_ERR_LIMIT. PT_FLAG_TIME_KERNELS is rejected
+ * (PT_ERR_INVALID). accum_dev is required; primary_id_dev and stats_out may be NULL.
+ * Every call on a GPU, from any context, shares that GPU's one array, which keeps the
+ * previous call's contents: each call re-initialises what must start at zero, and calls
+ * that overlap on one GPU (two streams, two contexts, two threads) race. */
+#define PT_NOALLOC_MAX_SLOTS 262144u
+PT_API int pt_render_accum_device_noalloc(pt_ctx* ctx, const pt_render_params* params,
+                                          float* accum_dev, uint32_t* primary_id_dev,
+                                          void* stream, pt_stats* stats_out);
 /* main.comp:616-619: divide by the valid-sample count, gamma, rgba8 store. */
 PT_API int pt_resolve_device(pt_ctx* ctx, const float* accum_dev, uint32_t pixel_count,
                              uint8_t* rgba8_dev, void* stream);

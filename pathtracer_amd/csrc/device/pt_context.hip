@@ -28,6 +28,33 @@ struct DevBuf {
   size_t bytes = 0;
 };
 
+// ---- scratch of pt_render_accum_device_noalloc: the per-slot path state, queues, queue counters and work-counter
+// table of ONE frame of at most PT_NOALLOC_MAX_SLOTS pixel slots, in a file-scope device array instead of hipMalloc'd
+// buffers. Each GPU the library runs on holds its own copy (at its own address) until the process ends. In host code
+// the NAME `scratch` is only a handle for hipGetSymbolAddress: the address every launch and memset uses is the
+// per-device pointer pt_create() looks up once, with that device current (g_scratch_ptr).
+constexpr uint32_t kNoAllocSlots = PT_NOALLOC_MAX_SLOTS;
+constexpr uint32_t kNoAllocStatRows = kNoAllocSlots / 64 * 2 + 16;
+constexpr size_t align256(size_t x) { return (x + 255) & ~static_cast<size_t>(255); }
+constexpr size_t kOffRayO = 0;
+constexpr size_t kOffRayD = kOffRayO + align256(16ull * kNoAllocSlots);
+constexpr size_t kOffPathA = kOffRayD + align256(16ull * kNoAllocSlots);
+constexpr size_t kOffPathB = kOffPathA + align256(16ull * kNoAllocSlots);
+constexpr size_t kOffAccum = kOffPathB + align256(16ull * kNoAllocSlots);
+constexpr size_t kOffPrimary = kOffAccum + align256(16ull * kNoAllocSlots);
+constexpr size_t kOffQueue0 = kOffPrimary + align256(4ull * kNoAllocSlots);
+constexpr size_t kOffQueue1 = kOffQueue0 + align256(4ull * kNoAllocSlots);
+constexpr size_t kOffCounters = kOffQueue1 + align256(4ull * kNoAllocSlots);
+constexpr size_t kOffStats = kOffCounters + align256(PT_CNT_WORDS * sizeof(uint32_t));
+constexpr size_t kOffTotals = kOffStats + align256(sizeof(unsigned long long) * PT_K_COUNT * kNoAllocStatRows * PT_ST_WORDS);
+constexpr size_t kScratchBytes = kOffTotals + align256(sizeof(unsigned long long) * PT_K_COUNT * PT_ST_WORDS);
+static_assert(kScratchBytes <= (32ull << 20), "scratch is meant to stay modest");
+
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+
+constexpr int kMaxDevices = 64;
+unsigned char* g_scratch_ptr[kMaxDevices] = {};  // per device: device address of that GPU's copy of `scratch`
+
 }  // namespace
 
 struct pt_ctx {
@@ -66,6 +93,8 @@ struct pt_ctx {
   uint32_t tail_entries = 262144;   // queue length below which the rest of the frame runs in one k_tail launch (0 = never)
   uint32_t lds_scene_bytes = 16384; // scenes up to this size (pair records + triangle positions) are staged whole in LDS
   uint32_t* host_counts = nullptr;  // pinned: [0..1] polled live-slot counts, from byte 64 on the work-counter totals
+  unsigned char* scratch = nullptr; // this device's copy of the file-scope scratch array (pt_render_accum_device_noalloc)
+  pt_dev_state scratch_state{};     // the scratch carved into the per-slot buffers of a frame of kNoAllocSlots slots
   hipEvent_t poll_events[2] = {nullptr, nullptr};
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   std::vector<hipEvent_t> kernel_events;
@@ -291,6 +320,37 @@ extern "C" pt_ctx* pt_create(int device) {
     pt_destroy(ctx);
     return nullptr;
   }
+  // The no-allocation entry point's scratch: once per device, with that device current (set above), look up where THIS
+  // GPU holds its copy of the file-scope array. Only this pointer is ever handed to a kernel, memset or copy.
+  if (device < kMaxDevices) {
+    if (!g_scratch_ptr[device]) {
+      void* sym = nullptr;
+      const hipError_t se = hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch));
+      if (se != hipSuccess || !sym) {
+        fail(nullptr, PT_ERR_DEVICE, "hipGetSymbolAddress(scratch) failed on device %d: %s", device, hipGetErrorString(se));
+        pt_destroy(ctx);
+        return nullptr;
+      }
+      g_scratch_ptr[device] = static_cast<unsigned char*>(sym);
+    }
+    ctx->scratch = g_scratch_ptr[device];
+    unsigned char* b = ctx->scratch;
+    pt_dev_state& ss = ctx->scratch_state;
+    ss.ray_o = reinterpret_cast<float4*>(b + kOffRayO);
+    ss.ray_d = reinterpret_cast<float4*>(b + kOffRayD);
+    ss.path_a = reinterpret_cast<float4*>(b + kOffPathA);
+    ss.path_b = reinterpret_cast<float4*>(b + kOffPathB);
+    ss.accum = reinterpret_cast<float4*>(b + kOffAccum);
+    ss.primary_id = reinterpret_cast<uint32_t*>(b + kOffPrimary);
+    ss.queue[0] = reinterpret_cast<uint32_t*>(b + kOffQueue0);
+    ss.queue[1] = reinterpret_cast<uint32_t*>(b + kOffQueue1);
+    ss.counters = reinterpret_cast<uint32_t*>(b + kOffCounters);
+    ss.stats = reinterpret_cast<unsigned long long*>(b + kOffStats);
+    ss.stat_totals = reinterpret_cast<unsigned long long*>(b + kOffTotals);
+    ss.stat_rows = kNoAllocStatRows;
+    ss.slot_stride = kNoAllocSlots;
+    // hit / pend / req / queue_shadow stay NULL: only the wavefront pipeline reads them and this entry point never runs it
+  }
   return ctx;
 }
 
@@ -489,8 +549,11 @@ hipEvent_t next_kernel_event(pt_ctx* ctx, size_t& used) {
   return ctx->kernel_events[used++];
 }
 
+// no_alloc: the frame's working set is the file-scope scratch array (ctx->scratch_state) and nothing is allocated on the way:
+// path pipeline only (the wavefront pipeline needs request buffers sized by the light count), no per-kernel timing
+// (its events are created on demand), outputs straight into the caller's buffers.
 int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint32_t* primary_dev, hipStream_t stream,
-                 pt_stats* stats_out) {
+                 pt_stats* stats_out, bool no_alloc = false) {
   if (!ctx->has_scene) return fail(ctx, PT_ERR_NO_SCENE, "pt_upload_scene has not been called");
   const pt_push_constants& pc = p->pc;
   if (!pc.resolution_x || !pc.resolution_y || pc.resolution_x > 65536 || pc.resolution_y > 65536)
@@ -534,13 +597,26 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
                                              : 0u;
   if (256u * sc.stack_entries * 4u + scene_lds > 65536u) sc.scene_in_lds = 0;  // deep tree: the stack needs the LDS
   const uint32_t trace_block = (256u * sc.stack_entries * 4u <= 65536u) ? 256u : 64u;
-  const int pipeline = ctx->pipeline;
+  const int pipeline = no_alloc ? 0 : ctx->pipeline;
   const bool split = pipeline == 1 && ctx->split_shadow && !sc.scene_in_lds && n_lights != 0;
-  int rc = ensure_state(ctx, band_slots, split ? n_lights : 0u, pixels);
-  if (rc != PT_OK) return rc;
-  const pt_dev_state& st = ctx->state;
-  if (!accum_dev) accum_dev = ctx->accum_out;
-  if (!primary_dev) primary_dev = ctx->primary_out;
+  int rc = PT_OK;
+  if (no_alloc) {
+    if (!ctx->scratch) return fail(ctx, PT_ERR_DEVICE, "no scratch array on device %d", ctx->device);
+    if (total_slots > kNoAllocSlots)
+      return fail(ctx, PT_ERR_LIMIT,
+                  "pt_render_accum_device_noalloc: %ux%u needs %u pixel slots (8x8 tiles), the fixed scratch holds %u "
+                  "(e.g. 512x512); use pt_render_accum_device",
+                  pc.resolution_x, pc.resolution_y, total_slots, kNoAllocSlots);
+    if (p->flags & PT_FLAG_TIME_KERNELS)
+      return fail(ctx, PT_ERR_INVALID, "pt_render_accum_device_noalloc: PT_FLAG_TIME_KERNELS creates events on demand; not available here");
+    band_slots = total_slots;
+  } else {
+    rc = ensure_state(ctx, band_slots, split ? n_lights : 0u, pixels);
+    if (rc != PT_OK) return rc;
+    if (!accum_dev) accum_dev = ctx->accum_out;
+    if (!primary_dev) primary_dev = ctx->primary_out;
+  }
+  const pt_dev_state& st = no_alloc ? ctx->scratch_state : ctx->state;
   const bool time_kernels = (p->flags & PT_FLAG_TIME_KERNELS) != 0;
   size_t ev_used = 0;
   std::vector<std::pair<size_t, int>> ev_kind;  // index of the start event, kernel id
@@ -707,6 +783,15 @@ extern "C" int pt_render_accum_device(pt_ctx* ctx, const pt_render_params* param
   PT_HIP(ctx, hipSetDevice(ctx->device));
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
   return render_accum(ctx, params, reinterpret_cast<float4*>(accum_dev), primary_id_dev, s, stats_out);
+}
+
+extern "C" int pt_render_accum_device_noalloc(pt_ctx* ctx, const pt_render_params* params, float* accum_dev,
+                                              uint32_t* primary_id_dev, void* stream, pt_stats* stats_out) {
+  if (!ctx) return PT_ERR_INVALID;
+  if (!params || !accum_dev) return fail(ctx, PT_ERR_INVALID, "params / accum_dev is NULL");
+  PT_HIP(ctx, hipSetDevice(ctx->device));
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+  return render_accum(ctx, params, reinterpret_cast<float4*>(accum_dev), primary_id_dev, s, stats_out, /*no_alloc=*/true);
 }
 
 extern "C" int pt_resolve_device(pt_ctx* ctx, const float* accum_dev, uint32_t pixel_count, uint8_t* rgba8_dev,
