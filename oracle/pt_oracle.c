@@ -556,6 +556,11 @@ static void get_material_data(shctx* c, uint32_t mat_idx, float tu, float tv, v3
 /* main.comp:263-304.  any_hit != 0 is the checker's mirror of the HIP path's shadow-ray
  * optimisation: stop at the first accepted triangle.  The visiting order is unchanged, so
  * "a hit exists" is decided identically; only the visit/test counters shrink. */
+/* Diagnostic (off unless a test sets it): visits per inner node, for sizing caches of the top of the tree.
+ * Relaxed increments from several threads may lose counts; use one thread for exact numbers. */
+static uint64_t* g_visit_hist = NULL;
+void orc_set_visit_histogram(uint64_t* per_node_counts) { g_visit_hist = per_node_counts; }
+
 static void ray_scene_intersect_ex(shctx* c, const ray_t* ray, isect_t* info, int any_hit) {
   ++c->st.rays;
   const pt_packed_bvh_node* nodes = c->sc->bvh_nodes;
@@ -571,6 +576,7 @@ static void ray_scene_intersect_ex(shctx* c, const ray_t* ray, isect_t* info, in
       }
     } else {
       ++c->st.node_visits;
+      if (g_visit_hist) ++g_visit_hist[(size_t)(node - nodes)];
       const pt_packed_bvh_node* left = &nodes[node->left_or_begin];
       const pt_packed_bvh_node* right = &nodes[node->left_or_begin + 1];
       float dist_left, dist_right;

@@ -52,6 +52,9 @@ int orc_scene_all_opaque(const pt_scene_desc* scene);
 /* main.comp:616-619 for one pixel's accumulator */
 void orc_resolve_pixel(float r, float g, float b, float valid, uint8_t* out_rgba);
 
+/* diagnostic: count visits per inner node into per_node_counts[bvh_node_count] (NULL = off) */
+void orc_set_visit_histogram(uint64_t* per_node_counts);
+
 uint32_t orc_triple32(uint32_t x);
 void orc_sincos(float x, float* s, float* c);
 float orc_pow(float x, float y);

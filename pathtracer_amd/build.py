@@ -20,7 +20,7 @@ CLI = os.path.join(HERE, "pathtracer")
 # to identical bits.  IEEE-correct fp32 divide and sqrt are hipcc's defaults for HIP.
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fvisibility=hidden",
           "-Wall", "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(CSRC, "device")]
-DEVICE_SRC = [os.path.join(CSRC, "device", f) for f in ("pt_kernels.hip", "pt_context.hip")]
+DEVICE_SRC = [os.path.join(CSRC, "device", f) for f in ("pt_kernels.hip", "pt_context.hip", "pt_sort.hip")]
 HOST_SRC = [os.path.join(CSRC, "host", f) for f in ("bvh_builder.cpp", "scene_pack.cpp")]
 
 

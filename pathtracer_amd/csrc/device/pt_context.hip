@@ -92,6 +92,16 @@ struct pt_ctx {
   bool split_shadow = true;         // scenes in global memory: shadow walks in their own kernel (PT_SPLIT_SHADOW=0 keeps them in k_shade)
   uint32_t tail_entries = 262144;   // queue length below which the rest of the frame runs in one k_tail launch (0 = never)
   uint32_t lds_scene_bytes = 16384; // scenes up to this size (pair records + triangle positions) are staged whole in LDS
+  uint32_t refill_thresh = 0;       // EXPERIMENT PT_EXTEND_REFILL: parked lanes that trigger a refill (0 = plain k_extend)
+  uint32_t refill_chunk = 256;      // PT_REFILL_CHUNK
+  uint32_t refill_blocks = 0;       // PT_REFILL_BLOCKS (0 = what is resident at once)
+  uint32_t sort_rays = 0;           // EXPERIMENT PT_SORT_RAYS: 1 = origin-major key, 2 = octant-major (wavefront pipeline only)
+  uint32_t sort_bits = 6;           // PT_SORT_BITS: origin cell bits per axis
+  uint32_t sort_shadow = 0;         // PT_SORT_SHADOW: also re-order the shadow queue
+  float scene_lo[3] = {0, 0, 0}, scene_hi[3] = {1, 1, 1};
+  uint32_t *sort_keys[2] = {nullptr, nullptr}, *sort_queue_out = nullptr, *sort_shadow_out = nullptr;
+  void* sort_temp = nullptr;
+  size_t sort_temp_bytes = 0;
   uint32_t* host_counts = nullptr;  // pinned: [0..1] polled live-slot counts, from byte 64 on the work-counter totals
   unsigned char* scratch = nullptr; // this device's copy of the file-scope scratch array (pt_render_accum_device_noalloc)
   pt_dev_state scratch_state{};     // the scratch carved into the per-slot buffers of a frame of kNoAllocSlots slots
@@ -237,6 +247,16 @@ int ensure_state(pt_ctx* ctx, uint32_t slots, uint32_t lights, uint32_t pixels) 
   st.stat_rows = slots / 64 * 2 + 16;  // >= the largest grid (64-thread blocks, rounded up to a multiple of 8)
   ALLOC(st.stats, static_cast<size_t>(PT_K_COUNT) * st.stat_rows * PT_ST_WORDS);
   ALLOC(st.stat_totals, static_cast<size_t>(PT_K_COUNT) * PT_ST_WORDS);
+  if (ctx->sort_rays) {
+    ALLOC(ctx->sort_keys[0], slots);
+    ALLOC(ctx->sort_keys[1], slots);
+    ALLOC(ctx->sort_queue_out, slots);
+    ALLOC(ctx->sort_shadow_out, slots);
+    ctx->sort_temp_bytes = ptd::sort_temp_bytes(slots);
+    unsigned char* tmp = nullptr;
+    if ((rc = dev_alloc(ctx, ctx->state_bufs, &tmp, ctx->sort_temp_bytes)) != PT_OK) return rc;
+    ctx->sort_temp = tmp;
+  }
   ALLOC(ctx->accum_out, pixels);
   ALLOC(ctx->primary_out, pixels);
   ALLOC(ctx->rgba8_out, pixels);
@@ -308,6 +328,15 @@ extern "C" pt_ctx* pt_create(int device) {
   if (const char* e = std::getenv("PT_COMPACT_EVERY")) ctx->compact_every = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   if (const char* e = std::getenv("PT_SPLIT_SHADOW")) ctx->split_shadow = std::strtoul(e, nullptr, 10) != 0;
   if (const char* e = std::getenv("PT_TAIL_ENTRIES")) ctx->tail_entries = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
+  if (const char* e = std::getenv("PT_EXTEND_REFILL")) ctx->refill_thresh = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
+  if (const char* e = std::getenv("PT_REFILL_CHUNK")) ctx->refill_chunk = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
+  if (const char* e = std::getenv("PT_REFILL_BLOCKS")) ctx->refill_blocks = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
+  if (ctx->refill_thresh > 64) ctx->refill_thresh = 64;
+  if (ctx->refill_chunk < 64) ctx->refill_chunk = 64;
+  if (const char* e = std::getenv("PT_SORT_RAYS")) ctx->sort_rays = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
+  if (const char* e = std::getenv("PT_SORT_BITS")) ctx->sort_bits = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
+  if (const char* e = std::getenv("PT_SORT_SHADOW")) ctx->sort_shadow = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
+  if (ctx->sort_bits < 1 || ctx->sort_bits > 9) ctx->sort_bits = 6;
   if (const char* e = std::getenv("PT_BAND_SLOTS")) ctx->band_slots = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   bool ok = hipSetDevice(device) == hipSuccess &&
             hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
@@ -514,6 +543,10 @@ extern "C" int pt_upload_scene(pt_ctx* ctx, const pt_scene_desc* s) {
         m.occlusion_texture_index != -1)
       d.any_texture = 1;
   }
+  for (int k = 0; k < 3; ++k) {  // scene bounds for the ray-sorting experiment: the root's box or the union of its children
+    ctx->scene_lo[k] = s->bvh_nodes[0].aabb_min[k];
+    ctx->scene_hi[k] = s->bvh_nodes[0].aabb_max[k];
+  }
   d.directional_light_count = s->directional_light_count;
   d.point_light_count = s->point_light_count;
   d.stack_entries = depth + 1;
@@ -693,12 +726,40 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
         for (uint32_t b = 0; b < kBatch; ++b, ++iter) {
           // the queue is rebuilt on the last iteration of a batch (every iteration in the split pipeline,
           // whose shadow queue is an append anyway) and re-used as it stands in between
-          const bool compact = split || ctx->compact_every <= 1 || (b + 1) % ctx->compact_every == 0 || b + 1 == kBatch;
-          timed(PT_K_EXTEND, [&] { ptd::launch_extend(sc, st, parity, bound, trace_block, ctx->trace_blocks, stream); });
+          const bool compact = split || ctx->sort_rays || ctx->compact_every <= 1 || (b + 1) % ctx->compact_every == 0 || b + 1 == kBatch;
+          if (ctx->sort_rays && iter > 0) {
+            // EXPERIMENT: k_extend walks the queue in (origin cell, octant) order; k_shade keeps the tile order
+            const uint32_t key_bits = 3u * ctx->sort_bits + 3u;
+            ptd::launch_ray_keys(st, st.queue[parity], PT_CNT_QUEUE0 + parity, bound, ctx->scene_lo, ctx->scene_hi, ctx->sort_bits,
+                                 ctx->sort_rays, ctx->sort_keys[0], st.ray_o, st.ray_d, stream);
+            if (ptd::sort_queue(ctx->sort_temp, ctx->sort_temp_bytes, ctx->sort_keys[0], ctx->sort_keys[1], st.queue[parity],
+                                ctx->sort_queue_out, bound, key_bits + 0u, stream) != 0)
+              return fail(ctx, PT_ERR_DEVICE, "radix sort failed");
+            pt_dev_state sorted = st;
+            sorted.queue[parity] = ctx->sort_queue_out;
+            timed(PT_K_EXTEND, [&] { ptd::launch_extend(sc, sorted, parity, bound, trace_block, ctx->trace_blocks, stream); });
+          } else if (ctx->refill_thresh && !sc.scene_in_lds && trace_block == 256) {
+            timed(PT_K_EXTEND, [&] {
+              ptd::launch_extend_refill(sc, st, parity, bound, ctx->refill_blocks, ctx->refill_chunk, ctx->refill_thresh, stream);
+            });
+          } else {
+            timed(PT_K_EXTEND, [&] { ptd::launch_extend(sc, st, parity, bound, trace_block, ctx->trace_blocks, stream); });
+          }
           timed(PT_K_SHADE, [&] {
             ptd::launch_shade(sc, f, st, parity, bound, trace_block, ctx->shade_blocks, n_lights != 0, split, compact, stream);
           });
-          if (split) timed(PT_K_SHADOW, [&] { ptd::launch_shadow(sc, f, st, bound, trace_block, ctx->trace_blocks, stream); });
+          if (split && ctx->sort_rays && ctx->sort_shadow) {
+            // shadow queue by the shadow origin (pend[2]) and the first light sample's direction (req[0])
+            const uint32_t key_bits = 3u * ctx->sort_bits + 3u;
+            ptd::launch_ray_keys(st, st.queue_shadow, PT_CNT_SHADOW, bound, ctx->scene_lo, ctx->scene_hi, ctx->sort_bits, ctx->sort_rays,
+                                 ctx->sort_keys[0], st.pend + 2 * static_cast<size_t>(st.slot_stride), st.req, stream);
+            if (ptd::sort_queue(ctx->sort_temp, ctx->sort_temp_bytes, ctx->sort_keys[0], ctx->sort_keys[1], st.queue_shadow,
+                                ctx->sort_shadow_out, bound, key_bits, stream) != 0)
+              return fail(ctx, PT_ERR_DEVICE, "radix sort failed");
+            pt_dev_state sorted = st;
+            sorted.queue_shadow = ctx->sort_shadow_out;
+            timed(PT_K_SHADOW, [&] { ptd::launch_shadow(sc, f, sorted, bound, trace_block, ctx->trace_blocks, stream); });
+          } else if (split) timed(PT_K_SHADOW, [&] { ptd::launch_shadow(sc, f, st, bound, trace_block, ctx->trace_blocks, stream); });
           if (compact) parity ^= 1u;
         }
         PT_HIP(ctx, hipGetLastError());

@@ -93,6 +93,14 @@ void launch_shadow(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_s
 void launch_paths(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity, uint32_t cnt_in,
                   uint32_t cnt_out, uint32_t cnt_zero, uint32_t max_entries, uint32_t block, uint32_t max_blocks,
                   uint32_t max_vertices, uint32_t xcd_chunk, hipStream_t s);
+void launch_extend_refill(const pt_dev_scene& sc, const pt_dev_state& st, uint32_t parity, uint32_t max_entries, uint32_t blocks,
+                          uint32_t chunk, uint32_t thresh, hipStream_t s);
+// experiment: ray re-ordering (pt_sort.hip)
+size_t sort_temp_bytes(uint32_t n);
+void launch_ray_keys(const pt_dev_state& st, const uint32_t* queue, uint32_t counter_word, uint32_t bound, const float* lo, const float* hi,
+                     uint32_t bits, uint32_t mode, uint32_t* keys, const float4* origin, const float4* dir, hipStream_t s);
+int sort_queue(void* temp, size_t temp_bytes, uint32_t* keys_in, uint32_t* keys_out, const uint32_t* q_in, uint32_t* q_out, uint32_t n,
+               uint32_t key_bits, hipStream_t s);
 void launch_sum_stats(const pt_dev_state& st, hipStream_t s);
 void launch_finalize(const pt_dev_frame& f, const pt_dev_state& st, float4* accum_out, uint32_t* primary_out, hipStream_t s);
 void launch_resolve(const float4* accum, uint32_t pixel_count, uint32_t* rgba8, hipStream_t s);

@@ -766,6 +766,121 @@ __global__ __launch_bounds__(256) void k_extend(pt_dev_scene sc, pt_dev_state st
   flush_tally(tally, st, PT_K_EXTEND);
 }
 
+// ---- one traversal in resumable form: the state a lane carries from trip to trip, and ONE trip of the
+// global-memory loop of traverse() (an inner visit, a leaf's triangle tests, or a pop — same order, same culls).
+struct TravState {
+  vec3 o, d, inv;
+  Hit h;
+  uint32_t ref, cnt, sp;
+};
+
+__device__ __forceinline__ void trav_begin(const Tracer& tr, vec3 o, vec3 d, TravState& s, Tally& tally) {
+  ++tally.rays;
+  s.o = o;
+  s.d = d;
+  s.inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+  s.h = Hit{kInfinity, 0.0f, 0.0f, kNoHit};
+  s.sp = tr.stack;
+  s.ref = tr.root_ref;
+  s.cnt = tr.root_cnt;
+}
+
+template <bool ANY_HIT>
+__device__ __forceinline__ bool trav_step(const Tracer& tr, TravState& s, Tally& tally) {  // false: the traversal has ended
+  if (s.cnt > 0) {
+    if (ANY_HIT) {
+      for (uint32_t i = 0; i < s.cnt; ++i) {
+        ++tally.tests;
+        ray_triangle<false>(tr, s.o, s.d, s.ref + i, s.h);
+        if (s.h.tri != kNoHit) return false;
+      }
+    } else {
+      tally.tests += s.cnt;
+      for (uint32_t i = 0; i < s.cnt; ++i) ray_triangle<false>(tr, s.o, s.d, s.ref + i, s.h);
+    }
+  } else {
+    ++tally.visits;
+    const float4 q0 = fetch16<false>(tr.pairs, 4 * s.ref), q1 = fetch16<false>(tr.pairs, 4 * s.ref + 1);
+    const float4 q2 = fetch16<false>(tr.pairs, 4 * s.ref + 2), q3 = fetch16<false>(tr.pairs, 4 * s.ref + 3);
+    float dist_l, dist_r;
+    bool hit_l, hit_r;
+    ray_box_pair(s.o, s.inv, q0, q1, q2, s.h.t, hit_l, hit_r, dist_l, dist_r);
+    if (hit_l || hit_r) {
+      const bool go_left = hit_l && (!hit_r || dist_l < dist_r);
+      if (hit_l && hit_r) {
+        stack_store(s.sp, (s.ref << 1) | (go_left ? 1u : 0u));
+        s.sp += tr.stride;
+      }
+      s.ref = go_left ? fbits(q3.x) : fbits(q3.z);
+      s.cnt = go_left ? fbits(q3.y) : fbits(q3.w);
+      return true;
+    }
+  }
+  if (s.sp == tr.stack) return false;
+  s.sp -= tr.stride;
+  const uint32_t e = stack_load(s.sp);
+  const uint2 c = fetch_child<false>(tr.pairs, e >> 1, e & 1u);
+  s.ref = c.x;
+  s.cnt = c.y;
+  return true;
+}
+
+// EXPERIMENT (PT_EXTEND_REFILL): k_extend for scenes in global memory as persistent waves with LANE REFILL. A wave owns
+// a stream of queue entries (chunks of `chunk` consecutive entries, dealt round-robin over the waves); a lane whose
+// traversal has ended parks until `thresh` lanes are parked, then all of them store their hit and take the next
+// entries of the stream. The wave's trips are then filled with ~64 - thresh/2 rays instead of the 15 of 64 that a
+// wave of fixed membership averages on these scenes (its slowest ray sets its trip count). Per ray nothing changes.
+__global__ __launch_bounds__(256) void k_extend_refill(pt_dev_scene sc, pt_dev_state st, uint32_t parity, uint32_t chunk, uint32_t thresh) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
+  const uint32_t n = st.counters[PT_CNT_QUEUE0 + parity];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st.counters[PT_CNT_QUEUE0 + (parity ^ 1u)] = 0;
+    st.counters[PT_CNT_SHADOW] = 0;
+  }
+  Tally tally;
+  const Tracer tr = make_tracer<false>(sc, lds_dyn);
+  const uint32_t waves_total = gridDim.x * (blockDim.x >> 6);
+  const uint32_t wave_gid = blockIdx.x * (blockDim.x >> 6) + wave_id();
+  auto queue_index = [&](uint32_t v) { return ((v / chunk) * waves_total + wave_gid) * chunk + v % chunk; };
+  uint32_t vnext = 0;  // wave-uniform
+  bool live = false, pending = false;
+  uint32_t slot = 0;
+  TravState s{};
+  bool exhausted = queue_index(0) >= n;
+  for (;;) {
+    const uint64_t idle = __ballot(!live);
+    const uint32_t n_idle = static_cast<uint32_t>(__popcll(idle));
+    if (!exhausted && n_idle >= thresh) {
+      if (!live) {
+        if (pending) {
+          st.hit[slot] = make_uint4(s.h.tri, fbits(s.h.u), fbits(s.h.v), fbits(s.h.t));
+          pending = false;
+        }
+        const uint32_t q = queue_index(vnext + mbcnt(idle));
+        if (q < n) {
+          slot = st.queue[parity][q];
+          const float4 d4 = st.ray_d[slot];
+          if (d4.w == 0.0f) {  // else: retired since the queue was last compacted
+            const float4 o4 = st.ray_o[slot];
+            trav_begin(tr, xyz(o4), xyz(d4), s, tally);
+            live = true;
+            pending = true;
+          }
+        }
+      }
+      vnext += n_idle;
+      exhausted = queue_index(vnext) >= n;  // the stream is monotonic in v: nothing left for this wave
+    }
+    if (__ballot(live) == 0) {
+      if (exhausted) break;
+      continue;
+    }
+    if (live) live = trav_step<false>(tr, s, tally);
+  }
+  if (pending) st.hit[slot] = make_uint4(s.h.tri, fbits(s.h.u), fbits(s.h.v), fbits(s.h.t));
+  flush_tally(tally, st, PT_K_EXTEND);
+}
+
 // ray_scene_intersect_with_transparency, main.comp:306-332. Returns the transparency and
 // leaves the last traversal's result in h.
 template <bool IN_LDS, bool ALL_OPAQUE, bool TEXTURED = true>
@@ -1399,6 +1514,22 @@ void launch_extend(const pt_dev_scene& sc, const pt_dev_state& st, uint32_t pari
   if (grid > max_blocks) grid = max_blocks;
   if (sc.scene_in_lds) hipLaunchKernelGGL(k_extend<true>, dim3(grid), dim3(block), trace_lds_bytes(sc, block), s, sc, st, parity);
   else hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(block), trace_lds_bytes(sc, block), s, sc, st, parity);
+}
+
+void launch_extend_refill(const pt_dev_scene& sc, const pt_dev_state& st, uint32_t parity, uint32_t max_entries, uint32_t blocks,
+                          uint32_t chunk, uint32_t thresh, hipStream_t s) {
+  const uint32_t block = 256;
+  const size_t lds = trace_lds_bytes(sc, block);
+  if (!blocks) {  // what is resident at once: a persistent grid
+    int per_cu = 0, cus = 0, dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_extend_refill, block, lds);
+    blocks = static_cast<uint32_t>(per_cu > 0 ? per_cu : 1) * static_cast<uint32_t>(cus > 0 ? cus : 256);
+  }
+  uint32_t grid = blocks_for(max_entries, block);
+  if (grid > blocks) grid = blocks;
+  hipLaunchKernelGGL(k_extend_refill, dim3(grid), dim3(block), lds, s, sc, st, parity, chunk, thresh);
 }
 
 void launch_shadow(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t max_entries, uint32_t block,
