@@ -362,6 +362,7 @@ def run_workload(be, name: str, steps: int, warmup: int, world: int, rank: int, 
         out["roofline"], out["kernels"] = roofline_of(sd, bool(sd["scene_in_lds"]), name, scene_bytes, bool(spp_override))
     if frame is not None:
         accum, ids, rgba = frame
+        out["_frame"] = frame
         gold_file = os.path.join(ROOT, "tests", "golden", f"{name}_full_digest.json")
         if name == "cornell1080":
             gold_file = os.path.join(ROOT, "tests", "golden", "cfg2_full_digest.json")
@@ -385,6 +386,58 @@ def run_workload(be, name: str, steps: int, warmup: int, world: int, rank: int, 
     return out
 
 
+def display(accum):
+    """Display-domain floats of an accumulator frame [N,4]: mean of the valid samples, gamma 1/2.2, clipped to [0,1]."""
+    import numpy as np
+    rgb = accum[:, :3].astype(np.float64) / np.maximum(accum[:, 3:4].astype(np.float64), 1.0)
+    return np.clip(rgb, 0.0, None) ** (1.0 / 2.2)
+
+
+def rel_mse(a, b, eps: float = 1e-2) -> float:
+    """relMSE = mean((a - b)^2 / (b^2 + eps)) on display-domain floats (clipped to [0,1])."""
+    import numpy as np
+    a, b = np.minimum(display(a), 1.0), np.minimum(display(b), 1.0)
+    return float(np.mean((a - b) ** 2 / (b * b + eps)))
+
+
+def fast_arith_leg(name: str, steps: int, exact_frame, exact_value: float) -> dict:
+    """The same workload on the opt-in fast-arithmetic build of the path kernel (PT_ARITH=fast: hardware rcp / sqrt / rsq /
+    exp2 / log2 / sin / cos and FMA contraction in the shading half), timed the same way and compared with the exact
+    frame by north_star's tolerance (relMSE <= 1e-3, primary-hit ids >= 99.99 %): what the bit-exact contract costs."""
+    import numpy as np
+    from pathtracer_amd import abi, scenes
+    os.environ["PT_ARITH"] = "fast"
+    try:
+        be = HipBackend(int(os.environ.get("LOCAL_RANK", "0")))  # the context reads PT_ARITH at creation
+    finally:
+        del os.environ["PT_ARITH"]
+    factory, kwargs, width, height, spp, _ = WORKLOADS[name]
+    packed = be.pack(getattr(scenes, factory)(**kwargs))
+    be.upload(packed)
+    rp = packed.render_params(be.lib, width, height, spp, BG.get(name, (0.239, 0.239, 0.239)), SEED)
+    be.alloc(width * height)
+    stats = abi.Stats()
+    be.render(rp, stats)  # warm-up
+    be.sync()
+    t0 = time.perf_counter()
+    rays = 0
+    for _ in range(steps):
+        be.render(rp, stats)
+        be.resolve()
+        rays += stats.rays
+    be.sync()
+    elapsed = time.perf_counter() - t0
+    be.render(rp, stats, want_ids=True)
+    accum, ids, _ = be.host_frame()
+    be.close()
+    e_accum, e_ids, _ = exact_frame
+    value = rays / elapsed / 1e6
+    return {"value": value, "unit": "Mrays/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
+            "speedup_over_exact": value / exact_value, "relmse_vs_exact": rel_mse(accum, e_accum), "relmse_tolerance": 1e-3,
+            "primary_id_agreement": float((ids == e_ids).mean()), "nan_samples": int(stats.nan_samples),
+            "note": "opt-in build (PT_ARITH=fast); the headline value above is the exact build, which is bit-identical to the oracle"}
+
+
 def main(argv=None, backend_factory=None) -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -398,6 +451,7 @@ def main(argv=None, backend_factory=None) -> None:
     ap.add_argument("--spp", type=int, default=0, help="override sample_count (dev only; invalidates the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the extra profiled step that feeds `roofline`")
+    ap.add_argument("--no-fast-arith", action="store_true", help="skip the PT_ARITH=fast comparison leg (N = 1 only)")
     ap.add_argument("--time-budget-s", type=float, default=420.0, help="extra configs are skipped once the run is this old")
     args = ap.parse_args(argv)
 
@@ -418,6 +472,13 @@ def main(argv=None, backend_factory=None) -> None:
 
     head = run_workload(be, args.workload, args.steps, args.warmup, world, rank, args.split, args.spp,
                         not args.no_kernel_timing, 0.0 if args.no_cpu_baseline else 12.0, dist)
+    fast = None
+    if (world == 1 and head is not None and "_frame" in head and not args.no_fast_arith and backend_factory is None
+            and not args.spp and os.environ.get("PT_ARITH") != "fast"):
+        progress(f"{args.workload}: the fast-arithmetic build")
+        fast = fast_arith_leg(args.workload, args.steps, head["_frame"], head["value"])
+    if head is not None:
+        head.pop("_frame", None)
     extras = []
     if world == 1 and args.configs != "none":
         for name in [c for c in args.configs.split(",") if c and c != args.workload]:
@@ -444,6 +505,11 @@ def main(argv=None, backend_factory=None) -> None:
                   "frame_properties_ok", "cpu_baseline"):
             if k in head:
                 out[k] = head[k]
+        if fast:
+            out["fast_arith"] = fast
+        for e in extras:
+            if e:
+                e.pop("_frame", None)
         if extras:
             out["configs"] = extras
         print(json.dumps(out))

@@ -14,6 +14,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpathtracer_amd.so")
 CLI = os.path.join(HERE, "pathtracer")
+OBJ_DIR = os.path.join(HERE, "build")  # intermediate objects (git-ignored)
 
 # -ffp-contract=off: the arithmetic contract — no FMA is ever formed, on the
 # host (BVH builder, camera) or the device, so CPU and GPU evaluate identical expressions
@@ -21,6 +22,7 @@ CLI = os.path.join(HERE, "pathtracer")
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fvisibility=hidden",
           "-Wall", "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(CSRC, "device")]
 DEVICE_SRC = [os.path.join(CSRC, "device", f) for f in ("pt_kernels.hip", "pt_context.hip", "pt_sort.hip")]
+FAST_SRC = os.path.join(CSRC, "device", "pt_kernels_fast.hip")
 HOST_SRC = [os.path.join(CSRC, "host", f) for f in ("bvh_builder.cpp", "scene_pack.cpp")]
 
 
@@ -48,10 +50,29 @@ def build(force: bool = False, verbose: bool = False) -> str:
     srcs = DEVICE_SRC + HOST_SRC + host_extra
     if force or _newer(LIB, srcs):
         extra = os.environ.get("PT_EXTRA_HIPCC_FLAGS", "").split()
-        cmd = [hipcc(), "--offload-arch=gfx950", "-shared", *COMMON, *extra, *srcs, "-o", os.environ.get("PT_LIB_OUT", LIB), "-lz", "-pthread"]
+        # every translation unit to its own object (in parallel), then one link. pt_kernels_fast.hip is the same kernel
+        # source with FMA contraction allowed: the fast-arithmetic build of the path kernel.
+        os.makedirs(OBJ_DIR, exist_ok=True)
+        fast_flags = [f if f != "-ffp-contract=off" else "-ffp-contract=fast" for f in COMMON]
+        jobs = [(src, COMMON) for src in srcs] + [(FAST_SRC, fast_flags)]
+        objs = []
+        cmds = []
+        for src, flags in jobs:
+            obj = os.path.join(OBJ_DIR, os.path.basename(src) + ".o")
+            objs.append(obj)
+            cmds.append([hipcc(), "--offload-arch=gfx950", "-c", *flags, *extra, src, "-o", obj])
         if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
+            for cmd in cmds:
+                print(" ".join(cmd))
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(8, len(cmds))) as pool:
+            for rc in pool.map(subprocess.call, cmds):
+                if rc != 0:
+                    raise subprocess.CalledProcessError(rc, "hipcc -c")
+        link = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", os.environ.get("PT_LIB_OUT", LIB), "-lz", "-pthread"]
+        if verbose:
+            print(" ".join(link))
+        subprocess.check_call(link)
     # the CLI: the reference's main.cc shape — front end + Renderer binding compiled as plain C++,
     # the device path reached only through the C ABI of the shared library
     main_cpp = os.path.join(CSRC, "host", "main.cpp")

@@ -83,6 +83,7 @@ struct pt_ctx {
   uint32_t trace_blocks = 0;        // grid cap of k_extend (persistent workgroups striding the queue)
   uint32_t shade_blocks = 0;        // grid cap of k_shade
   bool log_launches = false;        // PT_LOG_LAUNCHES: print the polled live-slot count of every launch to stderr
+  bool fast_arith = false;          // PT_ARITH=fast: k_paths of the fast-arithmetic build (path pipeline only; opt-in, not bit-exact)
   int pipeline = 0;                 // 0: path kernel (k_paths); 1: wavefront (k_extend + k_shade [+ k_shadow]); PT_PIPELINE=paths|wavefront
   uint32_t paths_vertices = 32;     // path vertices a slot advances per k_paths launch (PT_PATHS_VERTICES)
   uint32_t paths_blocks = 0xFFFFFFFFu; // grid cap of k_paths (PT_PATHS_BLOCKS)
@@ -315,6 +316,7 @@ extern "C" pt_ctx* pt_create(int device) {
   if (ctx->trace_blocks == 0) ctx->trace_blocks = 2048;
   if (ctx->lds_scene_bytes > 32768) ctx->lds_scene_bytes = 32768;
   ctx->log_launches = std::getenv("PT_LOG_LAUNCHES") != nullptr;
+  if (const char* e = std::getenv("PT_ARITH")) ctx->fast_arith = std::string(e) == "fast";
   if (const char* e = std::getenv("PT_PIPELINE")) ctx->pipeline = (std::string(e) == "wavefront") ? 1 : 0;
   if (const char* e = std::getenv("PT_PATHS_VERTICES")) ctx->paths_vertices = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   if (ctx->paths_vertices == 0) ctx->paths_vertices = 1;
@@ -711,7 +713,8 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
       uint64_t vertices = 0;
       for (uint32_t k = 0; !drained && vertices < max_iters; ++k, vertices += ctx->paths_vertices) {
         timed(PT_K_PATHS, [&] {
-          ptd::launch_paths(sc, f, st, k & 1u, PT_CNT_QUEUE0 + k % 3u, PT_CNT_QUEUE0 + (k + 1u) % 3u, PT_CNT_QUEUE0 + (k + 2u) % 3u, bound,
+          (ctx->fast_arith ? ptd_fast::launch_paths : ptd::launch_paths)(
+                            sc, f, st, k & 1u, PT_CNT_QUEUE0 + k % 3u, PT_CNT_QUEUE0 + (k + 1u) % 3u, PT_CNT_QUEUE0 + (k + 2u) % 3u, bound,
                             trace_block < ctx->paths_block_threads ? trace_block : ctx->paths_block_threads, ctx->paths_blocks,
                             ctx->paths_vertices, sc.scene_in_lds ? 0u : ctx->xcd_chunk, stream);
         });

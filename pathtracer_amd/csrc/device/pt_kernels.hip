@@ -25,6 +25,17 @@
 
 using namespace ptd;
 
+// This file is compiled twice: as it stands (the exact build: namespace ptd, every kernel) and, through
+// pt_kernels_fast.hip, with PT_FAST_ARITH defined and -ffp-contract=fast (the fast-arithmetic build of the path
+// kernel only: namespace ptd_fast, k_paths and launch_paths; see pt_vec.h for what "fast" changes).
+#ifdef PT_FAST_ARITH
+#define PT_KNS ptk_fast
+#define PT_LNS ptd_fast
+#else
+#define PT_KNS ptk_exact
+#define PT_LNS ptd
+#endif
+
 namespace {
 
 constexpr float kPi = 3.1415926535f;         // main.comp:13
@@ -166,6 +177,7 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void ray_box_pair(vec3 o, vec3 inv, const float4& q0, const float4& q1, const float4& q2, float t_best,
                                              bool& hit_l, bool& hit_r, float& dist_l, float& dist_r) {
+#pragma clang fp contract(off)
   // q0 = {lmin.x, rmin.x, lmin.y, rmin.y}, q1 = {lmin.z, rmin.z, lmax.x, rmax.x}, q2 = {lmax.y, rmax.y, lmax.z, rmax.z}:
   // every {left, right} operand pair of the packed instructions is an aligned register pair as loaded
   const f2 ox = {o.x, o.x}, oy = {o.y, o.y}, oz = {o.z, o.z};
@@ -238,23 +250,24 @@ __device__ __forceinline__ uint2 fetch_child(const float4* pairs, uint32_t rec, 
 // ray_triangle_intersect, main.comp:189-217
 template <bool IN_LDS>
 __device__ __forceinline__ void ray_triangle(const Tracer& tr, vec3 o, vec3 d, uint32_t tri, Hit& h) {
+#pragma clang fp contract(off)
   const vec3 p0 = xyz(fetch16<IN_LDS>(tr.tri_pos, 3 * tri));
-  const vec3 edge1 = xyz(fetch16<IN_LDS>(tr.tri_pos, 3 * tri + 1)) - p0;
-  const vec3 edge2 = xyz(fetch16<IN_LDS>(tr.tri_pos, 3 * tri + 2)) - p0;
-  const vec3 ray_cross_edge2 = cross(d, edge2);
-  const float det = dot(edge1, ray_cross_edge2);
+  const vec3 edge1 = sub_x(xyz(fetch16<IN_LDS>(tr.tri_pos, 3 * tri + 1)), p0);
+  const vec3 edge2 = sub_x(xyz(fetch16<IN_LDS>(tr.tri_pos, 3 * tri + 2)), p0);
+  const vec3 ray_cross_edge2 = cross_x(d, edge2);
+  const float det = dot_x(edge1, ray_cross_edge2);
   if (__builtin_fabsf(det) < kEpsilon) return;
 
   const float inv_det = 1.0f / det;
-  const vec3 s = o - p0;
-  const float u = inv_det * dot(s, ray_cross_edge2);
+  const vec3 s = sub_x(o, p0);
+  const float u = inv_det * dot_x(s, ray_cross_edge2);
   if (u < 0.0f || u > 1.0f) return;
 
-  const vec3 s_cross_edge1 = cross(s, edge1);
-  const float v = inv_det * dot(d, s_cross_edge1);
+  const vec3 s_cross_edge1 = cross_x(s, edge1);
+  const float v = inv_det * dot_x(d, s_cross_edge1);
   if (v < 0.0f || u + v > 1.0f) return;
 
-  const float t = inv_det * dot(edge2, s_cross_edge1);
+  const float t = inv_det * dot_x(edge2, s_cross_edge1);
   if (t > kEpsilon && t < h.t) {
     h.t = t;
     h.u = u;
@@ -529,8 +542,8 @@ __device__ __forceinline__ int wrap_coord(int i, int n, uint32_t mode) {
 
 __device__ __forceinline__ float4 texel(const uint32_t* __restrict__ texels, uint32_t base, int w, int x, int y) {
   const uint32_t p = texels[base + static_cast<uint32_t>(y) * static_cast<uint32_t>(w) + static_cast<uint32_t>(x)];
-  return make_float4(static_cast<float>(p & 255u) / 255.0f, static_cast<float>((p >> 8) & 255u) / 255.0f,
-                     static_cast<float>((p >> 16) & 255u) / 255.0f, static_cast<float>(p >> 24) / 255.0f);
+  return make_float4(sdiv(static_cast<float>(p & 255u), 255.0f), sdiv(static_cast<float>((p >> 8) & 255u), 255.0f),
+                     sdiv(static_cast<float>((p >> 16) & 255u), 255.0f), sdiv(static_cast<float>(p >> 24), 255.0f));
 }
 
 // sample_texture, main.comp:221-224
@@ -589,21 +602,21 @@ __device__ __forceinline__ float distribution_ggx(float n_dot_h, float a2) {
   if (a2 < kEpsilon && n_dot_h > 1.0f - kEpsilon) return 1.0f;
   float denom = n_dot_h * n_dot_h * (a2 - 1.0f) + 1.0f;
   denom = kPi * denom * denom;
-  return a2 / denom;
+  return sdiv(a2, denom);
 }
 
 __device__ __forceinline__ float geometry_smith1(vec3 n, vec3 h, vec3 x, float a2) {
   if (dot(h, x) <= 0.0f) return 0.0f;
   const float n_dot_x = dot(n, x);
-  const float denom = __builtin_fabsf(n_dot_x) + __builtin_sqrtf(a2 + (1.0f - a2) * n_dot_x * n_dot_x);
-  return 1.0f / denom;
+  const float denom = __builtin_fabsf(n_dot_x) + ssqrt(a2 + (1.0f - a2) * n_dot_x * n_dot_x);
+  return sdiv(1.0f, denom);
 }
 
 __device__ __forceinline__ vec3 microfacet_brdf(vec3 n, vec3 v, vec3 l, float metal, float a2, vec3 base_color) {
   const vec3 h = normalize(l + v);
   const float n_dot_h = gmax(dot(n, h), kEpsilon);
   const vec3 f0 = splat(0.04f) * (1.0f - metal) + base_color * metal;  // mix()
-  const vec3 f = f0 + (splat(1.0f) - f0) * pt_pow(1.0f - __builtin_fabsf(dot(v, h)), 5.0f);
+  const vec3 f = f0 + (splat(1.0f) - f0) * spow(1.0f - __builtin_fabsf(dot(v, h)), 5.0f);
   const vec3 diffuse = (splat(1.0f) - f) * (1.0f - metal) * base_color / kPi;
   // geometry_smith2(n, h, l, v, a2) at the call site: G1(l) * G1(v) with the roles as written (:353, :364)
   const float g2 = geometry_smith1(n, h, v, a2) * geometry_smith1(n, h, l, a2);
@@ -628,9 +641,9 @@ __device__ __forceinline__ vec3 to_world(const Basis& b, vec3 p) { return mat3_m
 __device__ __forceinline__ vec3 uniform_hemisphere_sampling(vec3 n, uint32_t& rng) {
   const float phi = 2.0f * kPi * rand_float(rng);
   const float cos_theta = 1.0f - rand_float(rng);
-  const float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
+  const float sin_theta = ssqrt(1.0f - cos_theta * cos_theta);
   float sp, cp;
-  pt_sincos(phi, &sp, &cp);
+  ssincos(phi, &sp, &cp);
   return to_world(orthogonal_matrix(n), mk(cp * sin_theta, sp * sin_theta, cos_theta));
 }
 
@@ -638,25 +651,25 @@ __device__ __forceinline__ vec3 diffuse_sample(vec3 n, const Basis& basis, uint3
   const float phi = 2.0f * kPi * rand_float(rng);
   const float rnd = rand_float(rng);
   float sp, cp;
-  pt_sincos(phi, &sp, &cp);
-  const float sr = __builtin_sqrtf(rnd);
-  const vec3 l = to_world(basis, mk(cp * sr, sp * sr, __builtin_sqrtf(1.0f - rnd)));
-  pdf = gmax(dot(n, l), 0.0f) / kPi;
+  ssincos(phi, &sp, &cp);
+  const float sr = ssqrt(rnd);
+  const vec3 l = to_world(basis, mk(cp * sr, sp * sr, ssqrt(1.0f - rnd)));
+  pdf = sdiv(gmax(dot(n, l), 0.0f), kPi);
   return l;
 }
 
 __device__ __forceinline__ vec3 microfacet_sample(const Basis& basis, vec3 v, float a2, uint32_t& rng, float& pdf) {
   const float phi = 2.0f * kPi * rand_float(rng);
   const float rnd = rand_float(rng);
-  const float cos2_theta = gmin(gmax((1.0f - rnd) / (rnd * (a2 - 1.0f) + 1.0f), 0.0f), 1.0f);
-  const float cos_theta = __builtin_sqrtf(cos2_theta);
-  const float sin_theta = __builtin_sqrtf(1.0f - cos2_theta);
+  const float cos2_theta = gmin(gmax(sdiv(1.0f - rnd, rnd * (a2 - 1.0f) + 1.0f), 0.0f), 1.0f);
+  const float cos_theta = ssqrt(cos2_theta);
+  const float sin_theta = ssqrt(1.0f - cos2_theta);
   float sp, cp;
-  pt_sincos(phi, &sp, &cp);
+  ssincos(phi, &sp, &cp);
   const vec3 h = normalize(to_world(basis, mk(cp * sin_theta, sp * sin_theta, cos_theta)));
   const vec3 i = -v;
   const vec3 l = i - h * (2.0f * dot(h, i));  // reflect(-v, h)
-  pdf = distribution_ggx(cos_theta, a2) * cos_theta / (4.0f * __builtin_fabsf(dot(h, l)));
+  pdf = sdiv(distribution_ggx(cos_theta, a2) * cos_theta, 4.0f * __builtin_fabsf(dot(h, l)));
   return l;
 }
 
@@ -694,6 +707,7 @@ __device__ __forceinline__ bool slot_to_pixel(const pt_dev_frame& f, uint32_t lo
 // Camera ray of stratum `sample` (main():599-605). Draws the x jitter first, then y.
 __device__ __forceinline__ void camera_ray(const pt_dev_frame& f, uint32_t x, uint32_t y, uint32_t sample, uint32_t& rng,
                                            vec3& origin, vec3& dir) {
+#pragma clang fp contract(off)
   const uint32_t n = f.sqrt_samples;
   const uint32_t sub_i = sample / n, sub_j = sample - sub_i * n;
   const float fn = static_cast<float>(n);
@@ -702,15 +716,17 @@ __device__ __forceinline__ void camera_ray(const pt_dev_frame& f, uint32_t x, ui
   const vec3 corner = mk(f.pc.corner_pixel_pos[0], f.pc.corner_pixel_pos[1], f.pc.corner_pixel_pos[2]);
   const vec3 du = mk(f.pc.pixel_delta_u[0], f.pc.pixel_delta_u[1], f.pc.pixel_delta_u[2]);
   const vec3 dv = mk(f.pc.pixel_delta_v[0], f.pc.pixel_delta_v[1], f.pc.pixel_delta_v[2]);
-  const vec3 pixel_center = corner + (static_cast<float>(x) + jx) * du + (static_cast<float>(y) + jy) * dv;
+  // (exact helpers: the primary rays, and with them the primary-hit ids, are the same in the exact and the fast build)
+  const vec3 pixel_center = madd_x(madd_x(corner, static_cast<float>(x) + jx, du), static_cast<float>(y) + jy, dv);
   origin = mk(f.pc.camera_position[0], f.pc.camera_position[1], f.pc.camera_position[2]);
-  dir = normalize(pixel_center - origin);
+  dir = normalize_x(sub_x(pixel_center, origin));
 }
 
 }  // namespace
 
 // =========================================================================== kernels
 
+#ifndef PT_FAST_ARITH
 // First sample of every slot; fills queue 0 with the live slots (compacted: padding slots
 // of partial tiles never enter a queue).
 __global__ __launch_bounds__(256) void k_init(pt_dev_frame f, pt_dev_state st) {
@@ -765,6 +781,8 @@ __global__ __launch_bounds__(256) void k_extend(pt_dev_scene sc, pt_dev_state st
   }
   flush_tally(tally, st, PT_K_EXTEND);
 }
+
+#endif  // !PT_FAST_ARITH
 
 // ---- one traversal in resumable form: the state a lane carries from trip to trip, and ONE trip of the
 // global-memory loop of traverse() (an inner visit, a leaf's triangle tests, or a pop — same order, same culls).
@@ -825,6 +843,7 @@ __device__ __forceinline__ bool trav_step(const Tracer& tr, TravState& s, Tally&
   return true;
 }
 
+#ifndef PT_FAST_ARITH
 // EXPERIMENT (PT_EXTEND_REFILL): k_extend for scenes in global memory as persistent waves with LANE REFILL. A wave owns
 // a stream of queue entries (chunks of `chunk` consecutive entries, dealt round-robin over the waves); a lane whose
 // traversal has ended parks until `thresh` lanes are parked, then all of them store their hit and take the next
@@ -880,6 +899,8 @@ __global__ __launch_bounds__(256) void k_extend_refill(pt_dev_scene sc, pt_dev_s
   if (pending) st.hit[slot] = make_uint4(s.h.tri, fbits(s.h.u), fbits(s.h.v), fbits(s.h.t));
   flush_tally(tally, st, PT_K_EXTEND);
 }
+
+#endif  // !PT_FAST_ARITH
 
 // ray_scene_intersect_with_transparency, main.comp:306-332. Returns the transparency and
 // leaves the last traversal's result in h.
@@ -1039,22 +1060,22 @@ __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const Shade
           n_dot_l = gmax(dot(nrm, l), 0.0f);
           a_factor = xyz(l0) * l0.w;
         } else {
-          correction = kNormalDelta / dot(l, nrm);
+          correction = sdiv(kNormalDelta, dot(l, nrm));
           limit = length(pos - sample_pos);
           n_dot_l = __builtin_fabsf(dot(nrm, l));
           if (kind == 1u) {
             a_factor = xyz(l0) * l0.w / kLightArea / kFourPi;
             const float cos_theta0 = dot(sample_dir, -l);
-            pdf = dist2 / (cos_theta0 * kLightArea);
+            pdf = sdiv(dist2, cos_theta0 * kLightArea);
           } else {
             const TriAttr at = load_attr<IN_LDS>(sd.tri_attr, etri);
             vec3 tri_n = normalize(mat3_mul(at.n0, at.n1, at.n2, ewuv));
             const float eu = at.u0 * ewuv.x + at.u1 * ewuv.y + at.u2 * ewuv.z;
             const float ev = at.v0 * ewuv.x + at.v1 * ewuv.y + at.v2 * ewuv.z;
             if (dot(l, tri_n) > 0.0f) tri_n = tri_n * -1.0f;
-            const float area = length(cross(xyz(q1) - xyz(q0), xyz(q2) - xyz(q0))) / 2.0f;
+            const float area = sdiv(length(cross(xyz(q1) - xyz(q0), xyz(q2) - xyz(q0))), 2.0f);
             const float cos_theta0 = dot(tri_n, -l);
-            pdf = dist2 / (cos_theta0 * area) / static_cast<float>(f.pc.emissive_triangle_count);
+            pdf = sdiv(sdiv(dist2, cos_theta0 * area), static_cast<float>(f.pc.emissive_triangle_count));
             Material emat = load_material<IN_LDS>(sd.materials, at.mat);
             if (!TEXTURED) emat.emissive_tex = -1;
             Tally uncounted;  // the reference fetches the emitter's texture only for visible samples: k_shadow counts the tap
@@ -1089,7 +1110,7 @@ __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const Shade
       const float transparency = shadow_walk<IN_LDS, ALL_OPAQUE, TEXTURED>(sc, sd, tr, shadow_origin, l, sh, walks);
       if (transparency == 0.0f) continue;
       if (kind != 0u) {
-        const float correction = kNormalDelta / dot(l, nrm);
+        const float correction = sdiv(kNormalDelta, dot(l, nrm));
         if (sh.tri != kNoHit && sh.t + correction < length(pos - sample_pos)) continue;
       }
       if (kind == 0u) {
@@ -1099,7 +1120,7 @@ __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const Shade
       } else if (kind == 1u) {
         const vec3 radiance = xyz(l0) * l0.w / kLightArea / kFourPi * transparency;
         const float cos_theta0 = dot(sample_dir, -l);
-        const float pdf = dist2 / (cos_theta0 * kLightArea);
+        const float pdf = sdiv(dist2, cos_theta0 * kLightArea);
         const float n_dot_l = __builtin_fabsf(dot(nrm, l));
         punctual = punctual + radiance * microfacet_brdf(nrm, view, l, metal, a2, base_color) * n_dot_l / pdf;
       } else {
@@ -1108,9 +1129,9 @@ __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const Shade
         const float eu = at.u0 * ewuv.x + at.u1 * ewuv.y + at.u2 * ewuv.z;
         const float ev = at.v0 * ewuv.x + at.v1 * ewuv.y + at.v2 * ewuv.z;
         if (dot(l, tri_n) > 0.0f) tri_n = tri_n * -1.0f;
-        const float area = length(cross(xyz(q1) - xyz(q0), xyz(q2) - xyz(q0))) / 2.0f;
+        const float area = sdiv(length(cross(xyz(q1) - xyz(q0), xyz(q2) - xyz(q0))), 2.0f);
         const float cos_theta0 = dot(tri_n, -l);
-        const float pdf = dist2 / (cos_theta0 * area) / static_cast<float>(f.pc.emissive_triangle_count);
+        const float pdf = sdiv(sdiv(dist2, cos_theta0 * area), static_cast<float>(f.pc.emissive_triangle_count));
         const float n_dot_l = __builtin_fabsf(dot(nrm, l));
         Material emat = load_material<IN_LDS>(sd.materials, at.mat);
             if (!TEXTURED) emat.emissive_tex = -1;
@@ -1225,6 +1246,7 @@ __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const Shade
 #ifndef PT_PATHS_MIN_WAVES_GLOBAL
 #define PT_PATHS_MIN_WAVES_GLOBAL 5  // scenes beyond an XCD's L2: swept 3..6 on cfg3/cfg4-class scenes, best at 5
 #endif
+#ifndef PT_FAST_ARITH
 // shade_vertex for every extended ray, then compaction of the survivors into the next queue.
 // Persistent workgroups striding the queue, so the LDS scene copy is staged once per block.
 template <bool IN_LDS, bool ALL_OPAQUE, bool SPLIT>
@@ -1367,6 +1389,8 @@ __global__ __launch_bounds__(256, ALL_OPAQUE ? PT_SHADOW_MIN_WAVES_OPAQUE : PT_S
   flush_tally(walks, st, PT_K_SHADOW);
 }
 
+#endif  // !PT_FAST_ARITH
+
 // The path kernel: every queued slot advances by up to `max_vertices` path vertices — extend,
 // shade (with its shadow walks), extend, ... — in ONE launch, its ray and path state held in
 // registers in between; then the survivors are compacted into the next queue. A pixel's samples
@@ -1379,6 +1403,7 @@ __global__ __launch_bounds__(256, ALL_OPAQUE ? PT_SHADOW_MIN_WAVES_OPAQUE : PT_S
 // Queue counters rotate over three words: this launch reads `cnt_in`, appends to `cnt_out` and
 // clears `cnt_zero` (the previous launch's input, the next launch's output) — no launch
 // clears a word that blocks of the same launch still have to read.
+namespace PT_KNS {
 template <bool IN_LDS, bool ALL_OPAQUE, int MIN_WAVES, bool PUNCTUAL, bool TEXTURED>
 __global__ __launch_bounds__(256, MIN_WAVES) void k_paths(pt_dev_scene sc, pt_dev_frame f, pt_dev_state st, uint32_t parity,
                                                                    uint32_t cnt_in, uint32_t cnt_out, uint32_t cnt_zero,
@@ -1441,6 +1466,10 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_paths(pt_dev_scene sc, pt_de
   flush_tally(walks, st, PT_K_SHADOW);
 }
 
+}  // namespace PT_KNS
+using namespace PT_KNS;
+
+#ifndef PT_FAST_ARITH
 // Column sums of the per-block counter table: one workgroup per kernel slice, so the host reads
 // PT_K_COUNT x PT_ST_WORDS words instead of the whole table (16 MB at 1080p: ~1.5 ms of the frame's wall time).
 __global__ __launch_bounds__(256) void k_sum_stats(pt_dev_state st) {
@@ -1489,15 +1518,20 @@ __global__ __launch_bounds__(256) void k_resolve(const float4* __restrict__ accu
   rgba8[i] = r | (g << 8) | (b << 16) | (255u << 24);
 }
 
+#endif  // !PT_FAST_ARITH
+
 // =========================================================================== launchers
 
-namespace ptd {
+namespace PT_LNS {
 
 static inline uint32_t blocks_for(uint32_t n, uint32_t block) { return n ? (n + block - 1) / block : 1u; }
 
+#ifndef PT_FAST_ARITH
 void launch_init(const pt_dev_frame& f, const pt_dev_state& st, hipStream_t s) {
   hipLaunchKernelGGL(k_init, dim3(blocks_for(f.slot_count, 256)), dim3(256), 0, s, f, st);
 }
+
+#endif
 
 static inline size_t trace_lds_bytes(const pt_dev_scene& sc, uint32_t block) {
   return static_cast<size_t>(block) * sc.stack_entries * sizeof(uint32_t) +
@@ -1508,6 +1542,7 @@ static inline size_t shade_lds_bytes(const pt_dev_scene& sc, uint32_t block) {
   return trace_lds_bytes(sc, block) + (sc.scene_in_lds ? 16u * static_cast<size_t>(shade_lds_float4s(sc)) : 0u);
 }
 
+#ifndef PT_FAST_ARITH
 void launch_extend(const pt_dev_scene& sc, const pt_dev_state& st, uint32_t parity, uint32_t max_entries, uint32_t block,
                    uint32_t max_blocks, hipStream_t s) {
   uint32_t grid = blocks_for(max_entries, block);
@@ -1560,6 +1595,8 @@ void launch_shade(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_st
   }
 }
 
+#endif
+
 void launch_paths(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity, uint32_t cnt_in,
                   uint32_t cnt_out, uint32_t cnt_zero, uint32_t max_entries, uint32_t block, uint32_t max_blocks,
                   uint32_t max_vertices, uint32_t xcd_chunk, hipStream_t s) {
@@ -1605,6 +1642,7 @@ void launch_paths(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_st
 #undef PT_LAUNCH_PATHS
 }
 
+#ifndef PT_FAST_ARITH
 void launch_sum_stats(const pt_dev_state& st, hipStream_t s) { hipLaunchKernelGGL(k_sum_stats, dim3(PT_K_COUNT), dim3(256), 0, s, st); }
 
 void launch_finalize(const pt_dev_frame& f, const pt_dev_state& st, float4* accum_out, uint32_t* primary_out, hipStream_t s) {
@@ -1615,4 +1653,6 @@ void launch_resolve(const float4* accum, uint32_t pixel_count, uint32_t* rgba8, 
   hipLaunchKernelGGL(k_resolve, dim3(blocks_for(pixel_count, 256)), dim3(256), 0, s, accum, pixel_count, rgba8);
 }
 
-}  // namespace ptd
+#endif
+
+}  // namespace PT_LNS
