@@ -1086,3 +1086,77 @@ void orc_sincos(float x, float* s, float* c) { pt_sincos(x, s, c); }
 float orc_pow(float x, float y) { return pt_pow(x, y); }
 float orc_exp2(float x) { return pt_exp2(x); }
 float orc_log2(float x) { return pt_log2_pos(x); }
+
+/* ---- per-function exports: the independent pins of tests/test_oracle_functions.py compare these with float32
+ * arithmetic written in the test from the GLSL text, with quadrature and with closed forms. Thin wrappers: the
+ * functions called are the ones the renderer above uses. */
+int orc_ray_aabb(const float* origin, const float* dir, const float* bmin, const float* bmax, float* t_near) {
+  ray_t r = { v3from(origin), v3from(dir) };
+  return ray_aabb_intersect(&r, bmin, bmax, t_near, 0);
+}
+
+/* tri = 3 x (x, y, z). Starts from info.t = t_in; returns 1 when the triangle was accepted (t, u, v written). */
+int orc_ray_triangle(const float* origin, const float* dir, const float* tri, float t_in, float* t, float* u, float* v) {
+  float pos[12] = { tri[0], tri[1], tri[2], 0.0f, tri[3], tri[4], tri[5], 0.0f, tri[6], tri[7], tri[8], 0.0f };
+  pt_scene_desc sc;
+  memset(&sc, 0, sizeof(sc));
+  sc.vertex_positions = pos;
+  sc.triangle_count = 1;
+  shctx c;
+  memset(&c, 0, sizeof(c));
+  c.sc = &sc;
+  ray_t r = { v3from(origin), v3from(dir) };
+  isect_t info = { t_in, 0.0f, 0.0f, ORC_NO_HIT };
+  ray_triangle_intersect(&c, &r, 0, &info);
+  if (info.tri_idx == ORC_NO_HIT) return 0;
+  *t = info.t; *u = info.u; *v = info.v;
+  return 1;
+}
+
+float orc_distribution_ggx(float n_dot_h, float a2) { return distribution_GGX(n_dot_h, a2); }
+float orc_geometry_smith1(const float* n, const float* h, const float* x, float a2) {
+  return geometry_smith1(v3from(n), v3from(h), v3from(x), a2);
+}
+void orc_microfacet_brdf(const float* n, const float* v, const float* l, float metal, float a2, const float* base_color, float* out) {
+  v3 r = microfacet_brdf(v3from(n), v3from(v), v3from(l), metal, a2, v3from(base_color));
+  out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+void orc_orthogonal_matrix(const float* w, float* out9) { /* columns u, v, w */
+  m3 m = orthogonal_matrix(v3from(w));
+  out9[0] = m.c0.x; out9[1] = m.c0.y; out9[2] = m.c0.z;
+  out9[3] = m.c1.x; out9[4] = m.c1.y; out9[5] = m.c1.z;
+  out9[6] = m.c2.x; out9[7] = m.c2.y; out9[8] = m.c2.z;
+}
+float orc_rand_float(uint32_t* state) {
+  shctx c;
+  memset(&c, 0, sizeof(c));
+  c.rand_state = *state;
+  float r = rand_float(&c);
+  *state = c.rand_state;
+  return r;
+}
+/* the three samplers: *state is the RNG state before and after (two draws each) */
+void orc_uniform_hemisphere_sampling(const float* n, uint32_t* state, float* out) {
+  shctx c;
+  memset(&c, 0, sizeof(c));
+  c.rand_state = *state;
+  v3 r = uniform_hemisphere_sampling(&c, v3from(n));
+  *state = c.rand_state;
+  out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+void orc_diffuse_sample(const float* n, uint32_t* state, float* out, float* pdf) {
+  shctx c;
+  memset(&c, 0, sizeof(c));
+  c.rand_state = *state;
+  v3 r = diffuse_sample(&c, v3from(n), pdf);
+  *state = c.rand_state;
+  out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}
+void orc_microfacet_sample(const float* n, const float* v, float a2, uint32_t* state, float* out, float* pdf) {
+  shctx c;
+  memset(&c, 0, sizeof(c));
+  c.rand_state = *state;
+  v3 r = microfacet_sample(&c, v3from(n), v3from(v), a2, pdf);
+  *state = c.rand_state;
+  out[0] = r.x; out[1] = r.y; out[2] = r.z;
+}

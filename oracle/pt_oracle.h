@@ -52,6 +52,19 @@ int orc_scene_all_opaque(const pt_scene_desc* scene);
 /* main.comp:616-619 for one pixel's accumulator */
 void orc_resolve_pixel(float r, float g, float b, float valid, uint8_t* out_rgba);
 
+/* Per-function exports for the independent pins (tests/test_oracle_functions.py): main.comp:169-185, 189-217,
+ * 336-366, 146-156, 370-405. Vectors are 3 floats; *state is the RNG state before and after. */
+int orc_ray_aabb(const float* origin, const float* dir, const float* bmin, const float* bmax, float* t_near);
+int orc_ray_triangle(const float* origin, const float* dir, const float* tri9, float t_in, float* t, float* u, float* v);
+float orc_distribution_ggx(float n_dot_h, float a2);
+float orc_geometry_smith1(const float* n, const float* h, const float* x, float a2);
+void orc_microfacet_brdf(const float* n, const float* v, const float* l, float metal, float a2, const float* base_color, float* out);
+void orc_orthogonal_matrix(const float* w, float* out9);
+float orc_rand_float(uint32_t* state);
+void orc_uniform_hemisphere_sampling(const float* n, uint32_t* state, float* out);
+void orc_diffuse_sample(const float* n, uint32_t* state, float* out, float* pdf);
+void orc_microfacet_sample(const float* n, const float* v, float a2, uint32_t* state, float* out, float* pdf);
+
 /* diagnostic: count visits per inner node into per_node_counts[bvh_node_count] (NULL = off) */
 void orc_set_visit_histogram(uint64_t* per_node_counts);
 

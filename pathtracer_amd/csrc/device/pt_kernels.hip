@@ -1444,6 +1444,9 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_paths(pt_dev_scene sc, pt_de
           primary = false;
           vec3 next_o = mk(0, 0, 0), next_d = mk(0, 0, 0);
           bool shaded;
+#ifdef PT_DIAG_LANES  // diagnostic build: texture_taps counts the wave-level calls of shade_vertex (lanes per call = rays_closest / taps)
+          if (mbcnt(__ballot(true)) == 0) ++tally.taps;
+#endif
           alive = shade_vertex<IN_LDS, ALL_OPAQUE, false, PUNCTUAL, TEXTURED>(sc, sd, f, st, tr, n_lights, bg_linear, slot, h, d, p,
                                                                               next_o, next_d, tally, walks, shaded);
           if (!alive) break;
