@@ -229,6 +229,7 @@ typedef struct pt_stats {
   uint64_t rays_shadow_shortcut; /* all-opaque scenes: area-light samples decided by the one-triangle test of
                                     the sampled emitter, without a tree walk (the reference traverses; the result
                                     is provably the same). 0 from the CPU oracle's reference mode. */
+  double   reduce_ms;            /* device group (pt_create_multi): time of the RCCL sum-reduce of the accumulators */
   uint64_t scene_in_lds;         /* 1: the scene was small enough to be staged whole in every workgroup's LDS
                                     (its fetches are LDS reads, not HBM traffic: the render is VALU-bound)      */
 } pt_stats;
@@ -246,6 +247,14 @@ PT_API int pt_device_name(int device, char* out, size_t out_size);
 /* Renderer::Renderer(device_index), src/renderer/renderer.h:24; device < 0 picks GPU 0
  * (the reference's -1 picks the first discrete GPU, renderer.cc:58-70). */
 PT_API pt_ctx* pt_create(int device);
+/* One context over several GPUs of THIS process (no counterpart in the single-device reference):
+ * the scene is replicated in every GPU's HBM by pt_upload_scene, pt_render gives rank i the strata
+ * [i n^2/n_dev, (i+1) n^2/n_dev) of every pixel (one host thread per GPU), sum-reduces the float4 accumulators to the
+ * first device with ONE ncclReduce over a communicator per GPU (ncclCommInitAll; RCCL is loaded with dlopen on the first
+ * call) and resolves there. With more than one device every rank draws from its own stream family, so
+ * the image is the same estimate, not the same bits, as a one-GPU render; with one device it is bit-identical to it.
+ * The other entry points (pt_render_accum_device, ...) act on the first device only. */
+PT_API pt_ctx* pt_create_multi(const int* device_ids, int n_devices);
 PT_API void pt_destroy(pt_ctx* ctx);
 
 /* Text of the last error on ctx (or of the last failed pt_create when ctx is NULL). */

@@ -4,12 +4,16 @@
 // hipMalloc / hipMemcpyAsync / kernel launches on one HIP stream.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and enums only: the functions are resolved with dlsym when pt_create_multi first needs them
+
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pathtracer_amd.h"
@@ -55,9 +59,54 @@ static __device__ __align__(256) unsigned char scratch[kScratchBytes];
 constexpr int kMaxDevices = 64;
 unsigned char* g_scratch_ptr[kMaxDevices] = {};  // per device: device address of that GPU's copy of `scratch`
 
+// RCCL, loaded on demand (pt_create_multi): one communicator per GPU of a single-process device group, used for exactly one
+// collective per frame — the sum-reduce of the float4 accumulators to the group's first GPU. No link-time
+// dependency: single-GPU users and the one-process-per-GPU path (torch.distributed) never load it through this library.
+struct RcclApi {
+  void* lib = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  std::string error;
+};
+
+RcclApi& rccl() {
+  static RcclApi api;
+  if (api.lib || !api.error.empty()) return api;
+  for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    if (api.lib) break;
+  }
+  if (!api.lib) {
+    api.error = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : "dlopen failed");
+    return api;
+  }
+  auto sym = [&](const char* n) {
+    void* p = dlsym(api.lib, n);
+    if (!p && api.error.empty()) api.error = std::string("librccl.so lacks ") + n;
+    return p;
+  };
+  api.CommInitAll = reinterpret_cast<decltype(api.CommInitAll)>(sym("ncclCommInitAll"));
+  api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(sym("ncclCommDestroy"));
+  api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
+  api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
+  api.Reduce = reinterpret_cast<decltype(api.Reduce)>(sym("ncclReduce"));
+  api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+  return api;
+}
+
 }  // namespace
 
 struct pt_ctx {
+  // device group (pt_create_multi): this context is rank 0; `members` lists every rank's context (this one first),
+  // `comms` their RCCL communicators. Empty for a plain pt_create context.
+  std::vector<pt_ctx*> members;
+  std::vector<ncclComm_t> comms;
+  double reduce_ms = 0.0;
+
   int device = 0;
   hipStream_t stream = nullptr;
   std::string err;
@@ -387,6 +436,15 @@ extern "C" pt_ctx* pt_create(int device) {
 
 extern "C" void pt_destroy(pt_ctx* ctx) {
   if (!ctx) return;
+  if (!ctx->members.empty()) {  // a device group: communicators first, then the other ranks' contexts
+    for (size_t i = 0; i < ctx->comms.size(); ++i)
+      if (ctx->comms[i] && rccl().CommDestroy) (void)rccl().CommDestroy(ctx->comms[i]);
+    ctx->comms.clear();
+    std::vector<pt_ctx*> members;
+    members.swap(ctx->members);
+    for (pt_ctx* m : members)
+      if (m != ctx) pt_destroy(m);
+  }
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   free_bufs(ctx->scene_bufs);
@@ -403,9 +461,23 @@ extern "C" void pt_destroy(pt_ctx* ctx) {
 
 extern "C" const char* pt_last_error(const pt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
+static int upload_one(pt_ctx* ctx, const pt_scene_desc* s);
+
 extern "C" int pt_upload_scene(pt_ctx* ctx, const pt_scene_desc* s) {
   if (!ctx) return PT_ERR_INVALID;
   if (!s) return fail(ctx, PT_ERR_INVALID, "scene is NULL");
+  if (ctx->members.empty()) return upload_one(ctx, s);
+  for (pt_ctx* m : ctx->members) {  // device group: the scene is replicated in every GPU's HBM
+    const int rc = upload_one(m, s);
+    if (rc != PT_OK) {
+      if (m != ctx) ctx->err = "device " + std::to_string(m->device) + ": " + m->err;
+      return rc;
+    }
+  }
+  return PT_OK;
+}
+
+static int upload_one(pt_ctx* ctx, const pt_scene_desc* s) {
   PT_HIP(ctx, hipSetDevice(ctx->device));
   uint32_t depth = 0;
   int rc = validate_scene(ctx, s, &depth);
@@ -869,12 +941,126 @@ extern "C" int pt_resolve_device(pt_ctx* ctx, const float* accum_dev, uint32_t p
   return PT_OK;
 }
 
+extern "C" pt_ctx* pt_create_multi(const int* device_ids, int n) {
+  if (!device_ids || n < 1 || n > kMaxDevices) {
+    fail(nullptr, PT_ERR_INVALID, "pt_create_multi: need 1..%d device ids", kMaxDevices);
+    return nullptr;
+  }
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < i; ++j)
+      if (device_ids[i] == device_ids[j]) {
+        fail(nullptr, PT_ERR_INVALID, "pt_create_multi: device %d listed twice", device_ids[i]);
+        return nullptr;
+      }
+  RcclApi& api = rccl();
+  if (!api.error.empty()) {
+    fail(nullptr, PT_ERR_DEVICE, "pt_create_multi: %s", api.error.c_str());
+    return nullptr;
+  }
+  std::vector<pt_ctx*> members;
+  for (int i = 0; i < n; ++i) {
+    pt_ctx* m = pt_create(device_ids[i] < 0 ? 0 : device_ids[i]);
+    if (!m) {
+      for (pt_ctx* x : members) pt_destroy(x);
+      return nullptr;  // pt_create left its message
+    }
+    members.push_back(m);
+  }
+  std::vector<int> devs;
+  for (pt_ctx* m : members) devs.push_back(m->device);
+  std::vector<ncclComm_t> comms(static_cast<size_t>(n), nullptr);
+  const ncclResult_t r = api.CommInitAll(comms.data(), n, devs.data());  // one communicator per GPU, this process owns all ranks
+  if (r != ncclSuccess) {
+    fail(nullptr, PT_ERR_DEVICE, "ncclCommInitAll over %d device(s) failed: %s", n, api.GetErrorString(r));
+    for (pt_ctx* x : members) pt_destroy(x);
+    return nullptr;
+  }
+  pt_ctx* root = members[0];
+  root->members = members;
+  root->comms = comms;
+  return root;
+}
+
+namespace {
+
+// pt_render over a device group: rank i renders strata [i n^2/R, (i+1) n^2/R) of every pixel on its own GPU (one host
+// thread per GPU: the render loop polls its stream), then ONE ncclReduce(sum, float32) of the float4 accumulators to
+// rank 0 over xGMI, which resolves. R = 1 runs the same code (a one-rank communicator), which is how a single-GPU box tests it.
+int render_group(pt_ctx* root, const pt_render_params* params, pt_stats* stats_out) {
+  const size_t R = root->members.size();
+  if (params->num_ranks > 1)
+    return fail(root, PT_ERR_INVALID, "a device group splits the strata itself: pass rank 0 / num_ranks 0 or 1, not %u / %u",
+                params->rank, params->num_ranks);
+  std::vector<pt_render_params> ps(R, *params);
+  std::vector<pt_stats> sts(R);
+  std::vector<int> rcs(R, PT_OK);
+  std::vector<std::thread> threads;
+  for (size_t i = 0; i < R; ++i) {
+    ps[i].rank = static_cast<uint32_t>(i);
+    ps[i].num_ranks = static_cast<uint32_t>(R);
+    threads.emplace_back([&, i] {
+      pt_ctx* m = root->members[i];
+      if (hipSetDevice(m->device) != hipSuccess) {
+        rcs[i] = fail(m, PT_ERR_DEVICE, "hipSetDevice(%d) failed", m->device);
+        return;
+      }
+      rcs[i] = render_accum(m, &ps[i], nullptr, nullptr, m->stream, &sts[i]);
+    });
+  }
+  for (std::thread& t : threads) t.join();
+  for (size_t i = 0; i < R; ++i)
+    if (rcs[i] != PT_OK) {
+      if (i) root->err = "device " + std::to_string(root->members[i]->device) + ": " + root->members[i]->err;
+      return rcs[i];
+    }
+  // the path's one exchange step
+  RcclApi& api = rccl();
+  const size_t count = 4 * static_cast<size_t>(params->pc.resolution_x) * params->pc.resolution_y;
+  PT_HIP(root, hipSetDevice(root->device));
+  PT_HIP(root, hipEventRecord(root->ev_start, root->stream));
+  ncclResult_t r = api.GroupStart();
+  for (size_t i = 0; i < R && r == ncclSuccess; ++i) {
+    pt_ctx* m = root->members[i];
+    r = api.Reduce(m->accum_out, m->accum_out, count, ncclFloat32, ncclSum, 0, root->comms[i], m->stream);  // in place; only rank 0's buffer receives
+  }
+  const ncclResult_t e = api.GroupEnd();
+  if (r == ncclSuccess) r = e;
+  if (r != ncclSuccess) return fail(root, PT_ERR_DEVICE, "ncclReduce of the accumulators failed: %s", api.GetErrorString(r));
+  PT_HIP(root, hipSetDevice(root->device));
+  PT_HIP(root, hipEventRecord(root->ev_stop, root->stream));
+  for (pt_ctx* m : root->members) {
+    PT_HIP(root, hipSetDevice(m->device));
+    PT_HIP(root, hipStreamSynchronize(m->stream));
+  }
+  PT_HIP(root, hipSetDevice(root->device));
+  float ms = 0.0f;
+  PT_HIP(root, hipEventElapsedTime(&ms, root->ev_start, root->ev_stop));
+  root->reduce_ms = ms;
+  if (stats_out) {  // work counters summed over the ranks; times of the slowest rank
+    *stats_out = sts[0];
+    for (size_t i = 1; i < R; ++i) {
+      const pt_stats& a = sts[i];
+      stats_out->paths += a.paths; stats_out->rays += a.rays; stats_out->node_visits += a.node_visits;
+      stats_out->tri_tests += a.tri_tests; stats_out->hits_shaded += a.hits_shaded; stats_out->texture_taps += a.texture_taps;
+      stats_out->shaded_vertices += a.shaded_vertices; stats_out->nan_samples += a.nan_samples;
+      stats_out->rays_closest += a.rays_closest; stats_out->rays_shadow_walked += a.rays_shadow_walked;
+      stats_out->rays_shadow_shortcut += a.rays_shadow_shortcut;
+      if (a.render_ms > stats_out->render_ms) stats_out->render_ms = a.render_ms;
+      if (a.iterations > stats_out->iterations) stats_out->iterations = a.iterations;
+    }
+    stats_out->reduce_ms = ms;
+  }
+  return PT_OK;
+}
+
+}  // namespace
+
 extern "C" int pt_render(pt_ctx* ctx, const pt_render_params* params, uint8_t* rgba8_out, float* accum_out,
                          uint32_t* primary_id_out, pt_stats* stats_out) {
   if (!ctx) return PT_ERR_INVALID;
   if (!params) return fail(ctx, PT_ERR_INVALID, "params is NULL");
   PT_HIP(ctx, hipSetDevice(ctx->device));
-  int rc = render_accum(ctx, params, nullptr, nullptr, ctx->stream, stats_out);
+  int rc = ctx->members.empty() ? render_accum(ctx, params, nullptr, nullptr, ctx->stream, stats_out) : render_group(ctx, params, stats_out);
   if (rc != PT_OK) return rc;
   const uint32_t pixels = params->pc.resolution_x * params->pc.resolution_y;
   PT_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));

@@ -1,12 +1,14 @@
 // pathtracer [config.json | list_devices] — the reference's CLI (src/main.cc:12-91) on the
 // HIP renderer. Same config keys (resolution_x, resolution_y, sample_count, bg_color as
 // [r,g,b] or "#RRGGBB", gltf_path, optional device_id); build-only optional keys: "seed"
-// (the reference's seed is not reproducible, Q4) and "stats" (true: print the work counters).
+// (the reference's seed is not reproducible, Q4), "stats" (true: print the work counters) and "num_gpus" (GPUs of this
+// node that split every pixel's strata).
 // Writes <gltf stem>.png into the current directory, like the reference.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
+#include <memory>
 #include <sstream>
 #include <string>
 
@@ -72,7 +74,10 @@ int main(int argc, char** argv) {
     uint32_t device_id = static_cast<uint32_t>(-1);
     if (config.contains("device_id")) device_id = static_cast<uint32_t>(config.at("device_id").as_int());
 
-    pt::Renderer renderer(device_id);
+    // build-only key: "num_gpus" (> 0: that many GPUs from device_id on share every pixel's strata, one RCCL sum-reduce)
+    const uint32_t num_gpus = config.contains("num_gpus") ? static_cast<uint32_t>(config.at("num_gpus").as_int()) : 0;
+    std::unique_ptr<pt::Renderer> renderer_holder(num_gpus ? new pt::Renderer(device_id, num_gpus) : new pt::Renderer(device_id));
+    pt::Renderer& renderer = *renderer_holder;
     if (config.contains("seed")) renderer.set_seed(static_cast<uint32_t>(config.at("seed").as_int()));
 
     const std::string gltf_path = config.at("gltf_path").as_string();
@@ -91,11 +96,11 @@ int main(int argc, char** argv) {
     if (config.contains("stats") && config.at("stats").boolean) {
       const pt_stats& st = renderer.stats();
       std::printf("{\"paths\": %llu, \"rays\": %llu, \"node_visits\": %llu, \"tri_tests\": %llu, \"render_ms\": %.3f, "
-                  "\"mrays_per_s\": %.1f, \"mpaths_per_s\": %.1f}\n",
+                  "\"mrays_per_s\": %.1f, \"mpaths_per_s\": %.1f, \"reduce_ms\": %.3f}\n",
                   static_cast<unsigned long long>(st.paths), static_cast<unsigned long long>(st.rays),
                   static_cast<unsigned long long>(st.node_visits), static_cast<unsigned long long>(st.tri_tests), st.render_ms,
                   st.render_ms > 0 ? static_cast<double>(st.rays) / st.render_ms / 1e3 : 0.0,
-                  st.render_ms > 0 ? static_cast<double>(st.paths) / st.render_ms / 1e3 : 0.0);
+                  st.render_ms > 0 ? static_cast<double>(st.paths) / st.render_ms / 1e3 : 0.0, st.reduce_ms);
     }
   } catch (const std::exception& e) {
     std::printf("Exception Occured: %s\n", e.what());  // main.cc:86-88 (and exit code 0, as the reference)

@@ -32,6 +32,15 @@ Renderer::Renderer(uint32_t device_index) {
   if (!ctx_) throw std::runtime_error(std::string("Failed to create the renderer: ") + pt_last_error(nullptr));
 }
 
+Renderer::Renderer(uint32_t device_index, uint32_t num_gpus) {
+  if (num_gpus == 0) num_gpus = 1;
+  const int first = device_index == static_cast<uint32_t>(-1) ? 0 : static_cast<int>(device_index);
+  std::vector<int> ids;
+  for (uint32_t i = 0; i < num_gpus; ++i) ids.push_back(first + static_cast<int>(i));
+  ctx_ = pt_create_multi(ids.data(), static_cast<int>(ids.size()));
+  if (!ctx_) throw std::runtime_error(std::string("Failed to create the renderer: ") + pt_last_error(nullptr));
+}
+
 Renderer::~Renderer() { pt_destroy(ctx_); }
 
 std::pair<const unsigned char*, size_t> Renderer::render(Scene& scene, const RenderConfig& config) {

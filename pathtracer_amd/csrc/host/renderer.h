@@ -25,6 +25,9 @@ struct RenderConfig {  // renderer.h:16-20
 class Renderer {
  public:
   explicit Renderer(uint32_t device_index = static_cast<uint32_t>(-1));  // renderer.h:24
+  // build-only: num_gpus GPUs of this node, device_index, device_index + 1, ... (config.json key "num_gpus"): the strata of
+  // every pixel are split over them and the accumulators sum-reduced with RCCL (pt_create_multi)
+  Renderer(uint32_t device_index, uint32_t num_gpus);
   ~Renderer();
   Renderer(const Renderer&) = delete;
   Renderer& operator=(const Renderer&) = delete;

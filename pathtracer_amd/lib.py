@@ -31,6 +31,8 @@ def load() -> C.CDLL:
         lib = C.CDLL(LIB_PATH)
         lib.pt_create.restype = C.c_void_p
         lib.pt_create.argtypes = [C.c_int]
+        lib.pt_create_multi.restype = C.c_void_p
+        lib.pt_create_multi.argtypes = [C.c_void_p, C.c_int]
         lib.pt_destroy.argtypes = [C.c_void_p]
         lib.pt_last_error.restype = C.c_char_p
         lib.pt_last_error.argtypes = [C.c_void_p]
