@@ -211,7 +211,12 @@ struct Tracer {
   uint32_t root_ref, root_cnt;
   uint32_t stack;         // LDS byte address of this lane's column of the traversal stack
   uint32_t stride;        // bytes from one level to the next
+  uint32_t stack_end;     // scenes in global memory: LDS byte address one past this lane's last LDS row; pushes beyond it go to private memory
 };
+
+// Rows of the traversal stack beyond a lane's LDS rows (scenes in global memory may run with a short LDS stack so that
+// more waves fit a CU): a private array, i.e. scratch memory, touched only by the rare ray whose stack outgrows the LDS rows.
+constexpr uint32_t kDeepLevels = 48;
 
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 __device__ __forceinline__ void stack_store(uint32_t addr, uint32_t v) { *reinterpret_cast<lds_u32*>(static_cast<uintptr_t>(addr)) = v; }
@@ -360,6 +365,8 @@ __device__ __forceinline__ void traverse(const Tracer& tr, vec3 o, vec3 d, Hit& 
         if (leaf()) return;
     }
   } else {
+    uint32_t deep[kDeepLevels];  // rows beyond the lane's LDS rows (private memory; nd counts them)
+    uint32_t nd = 0;
     for (;;) {
       if (cnt > 0) {
         if (ANY_HIT) {
@@ -382,17 +389,27 @@ __device__ __forceinline__ void traverse(const Tracer& tr, vec3 o, vec3 d, Hit& 
         if (hit_l || hit_r) {
           const bool go_left = hit_l && (!hit_r || dist_l < dist_r);
           if (hit_l && hit_r) {
-            stack_store(sp, (ref << 1) | (go_left ? 1u : 0u));
-            sp += tr.stride;
+            const uint32_t e = (ref << 1) | (go_left ? 1u : 0u);
+            if (sp != tr.stack_end) {
+              stack_store(sp, e);
+              sp += tr.stride;
+            } else {
+              deep[nd++] = e;
+            }
           }
           ref = go_left ? fbits(q3.x) : fbits(q3.z);
           cnt = go_left ? fbits(q3.y) : fbits(q3.w);
           continue;
         }
       }
-      if (sp == tr.stack) break;
-      sp -= tr.stride;
-      const uint32_t e = stack_load(sp);
+      uint32_t e;
+      if (nd != 0) {
+        e = deep[--nd];
+      } else {
+        if (sp == tr.stack) break;
+        sp -= tr.stride;
+        e = stack_load(sp);
+      }
       const uint2 c = fetch_child<IN_LDS>(tr.pairs, e >> 1, e & 1u);
       ref = c.x;
       cnt = c.y;
@@ -420,6 +437,8 @@ __device__ __forceinline__ Tracer make_tracer(const pt_dev_scene& sc, uint32_t* 
   tr.root_cnt = sc.root_cnt;
   tr.stack = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds + threadIdx.x));  // flat LDS address -> LDS offset (its low 32 bits)
   tr.stride = 4u * blockDim.x;
+  tr.stack_end = 0xFFFFFFFFu;
+  if (!IN_LDS) tr.stack_end = tr.stack + (sc.lds_stack_levels ? sc.lds_stack_levels : sc.stack_entries) * tr.stride;
   return tr;
 }
 
@@ -790,6 +809,7 @@ struct TravState {
   vec3 o, d, inv;
   Hit h;
   uint32_t ref, cnt, sp;
+  uint32_t nd;  // rows in the caller's private overflow array
 };
 
 __device__ __forceinline__ void trav_begin(const Tracer& tr, vec3 o, vec3 d, TravState& s, Tally& tally) {
@@ -799,12 +819,13 @@ __device__ __forceinline__ void trav_begin(const Tracer& tr, vec3 o, vec3 d, Tra
   s.inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
   s.h = Hit{kInfinity, 0.0f, 0.0f, kNoHit};
   s.sp = tr.stack;
+  s.nd = 0;
   s.ref = tr.root_ref;
   s.cnt = tr.root_cnt;
 }
 
 template <bool ANY_HIT>
-__device__ __forceinline__ bool trav_step(const Tracer& tr, TravState& s, Tally& tally) {  // false: the traversal has ended
+__device__ __forceinline__ bool trav_step(const Tracer& tr, TravState& s, uint32_t* deep, Tally& tally) {  // false: the traversal has ended
   if (s.cnt > 0) {
     if (ANY_HIT) {
       for (uint32_t i = 0; i < s.cnt; ++i) {
@@ -826,17 +847,27 @@ __device__ __forceinline__ bool trav_step(const Tracer& tr, TravState& s, Tally&
     if (hit_l || hit_r) {
       const bool go_left = hit_l && (!hit_r || dist_l < dist_r);
       if (hit_l && hit_r) {
-        stack_store(s.sp, (s.ref << 1) | (go_left ? 1u : 0u));
-        s.sp += tr.stride;
+        const uint32_t e = (s.ref << 1) | (go_left ? 1u : 0u);
+        if (s.sp != tr.stack_end) {
+          stack_store(s.sp, e);
+          s.sp += tr.stride;
+        } else {
+          deep[s.nd++] = e;
+        }
       }
       s.ref = go_left ? fbits(q3.x) : fbits(q3.z);
       s.cnt = go_left ? fbits(q3.y) : fbits(q3.w);
       return true;
     }
   }
-  if (s.sp == tr.stack) return false;
-  s.sp -= tr.stride;
-  const uint32_t e = stack_load(s.sp);
+  uint32_t e;
+  if (s.nd != 0) {
+    e = deep[--s.nd];
+  } else {
+    if (s.sp == tr.stack) return false;
+    s.sp -= tr.stride;
+    e = stack_load(s.sp);
+  }
   const uint2 c = fetch_child<false>(tr.pairs, e >> 1, e & 1u);
   s.ref = c.x;
   s.cnt = c.y;
@@ -865,6 +896,7 @@ __global__ __launch_bounds__(256) void k_extend_refill(pt_dev_scene sc, pt_dev_s
   bool live = false, pending = false;
   uint32_t slot = 0;
   TravState s{};
+  uint32_t deep[kDeepLevels];  // stack rows beyond the lane's LDS rows (private memory)
   bool exhausted = queue_index(0) >= n;
   for (;;) {
     const uint64_t idle = __ballot(!live);
@@ -894,7 +926,7 @@ __global__ __launch_bounds__(256) void k_extend_refill(pt_dev_scene sc, pt_dev_s
       if (exhausted) break;
       continue;
     }
-    if (live) live = trav_step<false>(tr, s, tally);
+    if (live) live = trav_step<false>(tr, s, deep, tally);
   }
   if (pending) st.hit[slot] = make_uint4(s.h.tri, fbits(s.h.u), fbits(s.h.v), fbits(s.h.t));
   flush_tally(tally, st, PT_K_EXTEND);
@@ -1537,8 +1569,9 @@ void launch_init(const pt_dev_frame& f, const pt_dev_state& st, hipStream_t s) {
 #endif
 
 static inline size_t trace_lds_bytes(const pt_dev_scene& sc, uint32_t block) {
-  return static_cast<size_t>(block) * sc.stack_entries * sizeof(uint32_t) +
-         (sc.scene_in_lds ? 64u * static_cast<size_t>(sc.pair_count) + 48u * static_cast<size_t>(sc.triangle_count) : 0u);
+  if (!sc.scene_in_lds) return static_cast<size_t>(block) * (sc.lds_stack_levels ? sc.lds_stack_levels : sc.stack_entries) * sizeof(uint32_t);
+  return static_cast<size_t>(block) * sc.stack_entries * sizeof(uint32_t) + 64u * static_cast<size_t>(sc.pair_count) +
+         48u * static_cast<size_t>(sc.triangle_count);
 }
 
 static inline size_t shade_lds_bytes(const pt_dev_scene& sc, uint32_t block) {

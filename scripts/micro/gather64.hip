@@ -23,6 +23,21 @@ __global__ __launch_bounds__(256) void walk_a(const float4* __restrict__ table, 
   out[blockIdx.x * blockDim.x + threadIdx.x] = ref + __float_as_uint(acc);
 }
 
+// A': as A, but the `active` walking lanes are spread over the wave (lane % (64 / active) == 0): one lane per quad at 16
+__global__ __launch_bounds__(256) void walk_s(const float4* __restrict__ table, uint32_t records, uint32_t steps, uint32_t active, uint32_t* out) {
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t ref = (blockIdx.x * blockDim.x + threadIdx.x) * 2654435761u % records;
+  float acc = 0.0f;
+  if (lane % (64u / active) == 0u) {
+    for (uint32_t s = 0; s < steps; ++s) {
+      const float4 a = table[4ull * ref], b = table[4ull * ref + 1], c = table[4ull * ref + 2], d = table[4ull * ref + 3];
+      acc += a.x + b.y + c.z + d.x;
+      ref = ((__float_as_uint(a.w) ^ __float_as_uint(c.w)) + (s + 1u) * 2246822519u + (blockIdx.x * blockDim.x + threadIdx.x) * 3266489917u) % records;
+    }
+  }
+  out[blockIdx.x * blockDim.x + threadIdx.x] = ref + __float_as_uint(acc);
+}
+
 __global__ __launch_bounds__(256) void walk_b(const float4* __restrict__ table, uint32_t records, uint32_t steps, uint32_t active, uint32_t* out) {
   __shared__ uint32_t refs[4][16];
   __shared__ float4 recs[4][16][4];
@@ -60,18 +75,19 @@ int main(int argc, char** argv) {
   CHECK(hipMemcpy(table, host.data(), 64ull * records, hipMemcpyHostToDevice));
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (uint32_t active : {4u, 8u, 16u, 64u}) {
-    for (int variant = 0; variant < 2; ++variant) {
-      if (variant == 1 && active > 16) continue;
+    for (int variant = 0; variant < 3; ++variant) {
+      if (variant >= 1 && active > 16) continue;
       float best = 1e30f;
       for (int rep = 0; rep < 3; ++rep) {
         hipEventRecord(e0);
-        if (variant == 0) hipLaunchKernelGGL(walk_a, dim3(blocks), dim3(256), 0, 0, table, records, steps, active, out);
+        if (variant == 2) hipLaunchKernelGGL(walk_s, dim3(blocks), dim3(256), 0, 0, table, records, steps, active, out);
+        else if (variant == 0) hipLaunchKernelGGL(walk_a, dim3(blocks), dim3(256), 0, 0, table, records, steps, active, out);
         else hipLaunchKernelGGL(walk_b, dim3(blocks), dim3(256), 0, 0, table, records, steps, active, out);
         hipEventRecord(e1); CHECK(hipEventSynchronize(e1));
         float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
       }
       const double fetches = double(blocks) * 4 * active * steps;
-      printf("active %2u  %s  %8.3f ms  %7.2f Grecords/s  %7.1f GB/s\n", active, variant ? "coop" : "lane", best, fetches / best / 1e6, fetches * 64 / best / 1e6);
+      printf("active %2u  %s  %8.3f ms  %7.2f Grecords/s  %7.1f GB/s\n", active, variant == 2 ? "scat" : (variant ? "coop" : "lane"), best, fetches / best / 1e6, fetches * 64 / best / 1e6);
     }
   }
   return 0;
