@@ -11,7 +11,7 @@ while read -r set; do
   [ -z "$set" ] && continue
   i=$((i+1))
   echo "== pass $i: $set"
-  timeout -s KILL 240 rocprofv3 --pmc $set --output-format csv -d "$out/pass$i" -- python3 bench.py --steps 1 --warmup 0 --configs none --no-cpu-baseline --no-kernel-timing "$@" > "$out/pass$i.log" 2>&1 || { echo "pass $i failed"; tail -5 "$out/pass$i.log"; exit 1; }
+  timeout -s KILL 240 rocprofv3 --pmc $set --output-format csv -d "$out/pass$i" -- python3 bench.py --steps 1 --warmup 0 --configs none --no-fast-arith --no-cpu-baseline --no-kernel-timing "$@" > "$out/pass$i.log" 2>&1 || { echo "pass $i failed"; tail -5 "$out/pass$i.log"; exit 1; }
 done <<'SETS'
 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY
 SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_ACTIVE_INST_ANY SQ_INSTS_LDS

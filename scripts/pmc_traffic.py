@@ -14,6 +14,9 @@ for f in sorted(glob.glob(os.path.join(src, "pass*", "**", "*counter_collection.
         if row["Counter_Name"] not in ("FETCH_SIZE", "WRITE_SIZE"):
             continue
         k = row["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+        if k.startswith("ptk_fast::"):
+            continue  # the opt-in fast-arithmetic build's leg of bench.py, if it ran
+        k = k.replace("ptk_exact::", "")
         tot[k][row["Counter_Name"]] += float(row["Counter_Value"])
         disp[k][row["Counter_Name"]].add(row["Dispatch_Id"])
 res = {"workload": name, "source": src, "correction": "bytes = 2 * FETCH_SIZE KiB * 1024 + WRITE_SIZE KiB * 1024", "kernels": {}}
