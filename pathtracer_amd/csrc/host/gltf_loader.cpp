@@ -314,14 +314,22 @@ class Loader {
     const int64_t buf = bv.int_or("buffer", 0);
     if (buf < 0 || static_cast<size_t>(buf) >= buffers_.size()) throw std::runtime_error("glTF: buffer index out of range");
     View v;
-    v.count = static_cast<size_t>(a.int_or("count", 0));
+    // counts and offsets come from the file: negative values are rejected before any cast, and the range check is written
+    // so that nothing in it can wrap (count - 1 <= (size - offset - element_size) / stride)
+    const int64_t count = a.int_or("count", 0), byte_stride = bv.int_or("byteStride", 0);
+    const int64_t off_a = a.int_or("byteOffset", 0), off_v = bv.int_or("byteOffset", 0);
+    if (count < 0 || byte_stride < 0 || off_a < 0 || off_v < 0) throw std::runtime_error("glTF: negative count / offset / stride in an accessor");
+    v.count = static_cast<size_t>(count);
     v.component_type = static_cast<int>(a.int_or("componentType", 0));
     v.type = a.at("type").as_string();
-    const size_t stride = static_cast<size_t>(bv.int_or("byteStride", 0));
+    const size_t stride = static_cast<size_t>(byte_stride);
     v.stride = stride ? stride : element_size;
-    const size_t offset = static_cast<size_t>(a.int_or("byteOffset", 0)) + static_cast<size_t>(bv.int_or("byteOffset", 0));
     const std::vector<unsigned char>& data = buffers_[static_cast<size_t>(buf)];
-    if (v.count && offset + (v.count - 1) * v.stride + element_size > data.size())
+    const size_t size = data.size();
+    if (static_cast<uint64_t>(off_a) > size || static_cast<uint64_t>(off_v) > size - static_cast<size_t>(off_a))
+      throw std::runtime_error("glTF: accessor reads past the end of its buffer");
+    const size_t offset = static_cast<size_t>(off_a) + static_cast<size_t>(off_v);
+    if (v.count && (element_size > size - offset || (v.count - 1) > (size - offset - element_size) / v.stride))
       throw std::runtime_error("glTF: accessor reads past the end of its buffer");
     v.ptr = data.data() + offset;
     return v;
