@@ -89,7 +89,7 @@ __device__ __forceinline__ uint32_t mbcnt(uint64_t mask) {  // set bits of `mask
 // Queue compaction, two queues at once: ballot + mbcnt inside a wave, a 4-entry LDS scan
 // across the block's waves, ONE returning atomic per block and queue (a single hot word
 // saturates near 90 atomics/us on MI355X, so per-wave atomics would bound the kernel).
-// Every thread of the block must call it (converged). Blocks are 256 threads = 4 waves.
+// Every thread of the block must call it (converged). Blocks have 1 to 4 waves (k_paths runs 64-thread blocks).
 struct AppendSlots {
   uint32_t a, b;
 };
@@ -1437,6 +1437,8 @@ __global__ __launch_bounds__(256, ALL_OPAQUE ? PT_SHADOW_MIN_WAVES_OPAQUE : PT_S
 // clears a word that blocks of the same launch still have to read.
 namespace PT_KNS {
 template <bool IN_LDS, bool ALL_OPAQUE, int MIN_WAVES, bool PUNCTUAL, bool TEXTURED>
+// (launched with 64-, 128- or 256-thread blocks: the bound states the largest; MIN_WAVES = waves per SIMD the register
+// allocator must leave room for, which is what sets the occupancy at any of those block sizes)
 __global__ __launch_bounds__(256, MIN_WAVES) void k_paths(pt_dev_scene sc, pt_dev_frame f, pt_dev_state st, uint32_t parity,
                                                                    uint32_t cnt_in, uint32_t cnt_out, uint32_t cnt_zero,
                                                                    uint32_t max_vertices, uint32_t xcd_chunk) {

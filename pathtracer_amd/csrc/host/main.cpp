@@ -18,18 +18,7 @@
 
 namespace {
 
-template <class F>
-void timeit(const char* info, F&& f) {  // src/timeit.h
-  std::printf("%-16s -> ", info);
-  std::fflush(stdout);
-  const auto t1 = std::chrono::steady_clock::now();
-  f();
-  const auto t2 = std::chrono::steady_clock::now();
-  const long long ms = std::chrono::duration_cast<std::chrono::milliseconds>(t2 - t1).count();
-  if (ms < 100) std::printf("%lldms\n", ms);
-  else if (ms < 10000) std::printf("%.2gs\n", static_cast<double>(ms) / 1000.0);
-  else std::printf("%llds\n", ms / 1000);
-}
+using pt::timeit;
 
 std::string stem_of(const std::string& path) {  // std::filesystem::path(p).stem()
   const size_t slash = path.find_last_of("/\\");

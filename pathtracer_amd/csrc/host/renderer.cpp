@@ -7,23 +7,6 @@
 
 namespace pt {
 
-namespace {
-
-// timeit(), src/timeit.h:5-24 (same output format: "{:<16} -> " + ms / s)
-template <class F>
-void timeit(const char* info, F&& f) {
-  std::printf("%-16s -> ", info);
-  std::fflush(stdout);
-  const auto t1 = std::chrono::steady_clock::now();
-  f();
-  const auto t2 = std::chrono::steady_clock::now();
-  const long long ms = std::chrono::duration_cast<std::chrono::milliseconds>(t2 - t1).count();
-  if (ms < 100) std::printf("%lldms\n", ms);
-  else if (ms < 10000) std::printf("%.2gs\n", static_cast<double>(ms) / 1000.0);
-  else std::printf("%llds\n", ms / 1000);
-}
-
-}  // namespace
 
 Renderer::Renderer(uint32_t device_index) {
   // the reference honours only ids > 0 and otherwise takes the first discrete GPU

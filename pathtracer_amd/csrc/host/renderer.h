@@ -3,7 +3,9 @@
 // theirs and main.cc keeps compiling.
 #pragma once
 
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -50,5 +52,19 @@ class Renderer {
 };
 
 void list_devices();  // renderer.h:55
+
+// timeit(), src/timeit.h:5-24 (same output format: "{:<16} -> " + ms / s); shared by the CLI and the Renderer binding
+template <class F>
+void timeit(const char* info, F&& f) {
+  std::printf("%-16s -> ", info);
+  std::fflush(stdout);
+  const auto t1 = std::chrono::steady_clock::now();
+  f();
+  const auto t2 = std::chrono::steady_clock::now();
+  const long long ms = std::chrono::duration_cast<std::chrono::milliseconds>(t2 - t1).count();
+  if (ms < 100) std::printf("%lldms\n", ms);
+  else if (ms < 10000) std::printf("%.2gs\n", static_cast<double>(ms) / 1000.0);
+  else std::printf("%llds\n", ms / 1000);
+}
 
 }  // namespace pt
