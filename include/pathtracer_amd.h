@@ -384,7 +384,7 @@ PT_API const char* pt_host_last_error(void);
 
 /* stbi_write_png(path, w, h, 4, data, stride), src/main.cc:78-83 */
 PT_API int pt_write_png(const char* path, uint32_t width, uint32_t height, const uint8_t* rgba8, uint32_t stride_bytes);
-/* stb_image decode as tinygltf configures it (4 x 8-bit): PNG only in this build. rgba8_out
+/* stb_image decode as tinygltf configures it (4 x 8-bit): PNG and baseline JPEG in this build. rgba8_out
  * may be NULL to query the size. */
 PT_API int pt_decode_image(const uint8_t* bytes, size_t size, uint32_t* width, uint32_t* height,
                            uint8_t* rgba8_out, size_t out_capacity);

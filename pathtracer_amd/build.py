@@ -76,7 +76,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     # the CLI: the reference's main.cc shape — front end + Renderer binding compiled as plain C++,
     # the device path reached only through the C ABI of the shared library
     main_cpp = os.path.join(CSRC, "host", "main.cpp")
-    cli_src = [main_cpp] + [os.path.join(CSRC, "host", f) for f in ("renderer.cpp", "gltf_loader.cpp", "image_io.cpp")]
+    cli_src = [main_cpp] + [os.path.join(CSRC, "host", f) for f in ("renderer.cpp", "gltf_loader.cpp", "image_io.cpp", "jpeg_decode.cpp")]
     if os.path.exists(main_cpp) and (force or _newer(CLI, cli_src + [LIB])):
         cmd = ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-Wall", "-I", os.path.join(ROOT, "include"), *cli_src,
                "-o", CLI, "-L", HERE, "-lpathtracer_amd", "-lz", "-Wl,-rpath,$ORIGIN"]

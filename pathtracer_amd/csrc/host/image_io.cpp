@@ -110,8 +110,10 @@ void store_pixel(const PngInfo& info, const unsigned char* row, uint32_t x, unsi
 void decode_image_rgba8(const unsigned char* bytes, size_t size, uint32_t& width, uint32_t& height,
                         std::vector<unsigned char>& rgba) {
   static const unsigned char kSig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
-  if (size >= 3 && bytes[0] == 0xFF && bytes[1] == 0xD8)
-    throw std::runtime_error("JPEG images are not supported by this build (PNG only); re-encode the texture as PNG");
+  if (size >= 3 && bytes[0] == 0xFF && bytes[1] == 0xD8) {  // JPEG: jpeg_decode.cpp (baseline sequential only)
+    decode_jpeg_rgba8(bytes, size, width, height, rgba);
+    return;
+  }
   if (size < 8 || std::memcmp(bytes, kSig, 8) != 0) throw std::runtime_error("unsupported image container (PNG expected)");
 
   PngInfo info;

@@ -287,7 +287,36 @@ def test_png_decode_grey_rgb_palette_and_16bit(ptlib):
     assert out[0, 0].tolist() == [0x12, 0xAB, 0x00, 0xFF]
 
 
-def test_jpeg_and_garbage_rejected(ptlib):
+def test_baseline_jpeg_decode_against_libjpeg(ptlib):
+    """Baseline JPEG textures (what the reference reads through tinygltf / stb_image). A lossy codec's pixels are
+    decoder-defined (IDCT rounding, chroma upsampling): this decoder stays within 3 code values of libjpeg (PIL) on
+    4:4:4, 4:2:2, 4:2:0, greyscale and restart-interval streams; parity with stb_image's exact bits is unpinned."""
+    import io
+    from PIL import Image
+    y, x = np.mgrid[0:67, 0:93]
+    img = np.stack([128 + 100 * np.sin(x / 9.0) * np.cos(y / 7.0), 128 + 90 * np.cos(x / 5.0 + y / 11.0), (x * 2 + y) % 256], -1)
+    img = img.clip(0, 255).astype(np.uint8)
+    cases = [dict(subsampling=0), dict(subsampling=1), dict(subsampling=2), dict(subsampling=2, restart_marker_blocks=3),
+             dict(subsampling=0, quality=35), None]
+    for kw in cases:
+        b = io.BytesIO()
+        if kw is None:
+            Image.fromarray(img[..., 0]).save(b, "JPEG", quality=90)
+        else:
+            Image.fromarray(img).save(b, "JPEG", **{"quality": 90, **kw})
+        data = b.getvalue()
+        ref = np.array(Image.open(io.BytesIO(data)).convert("RGB")).astype(int)
+        got = frontend.decode_image(data)
+        assert got.shape == (67, 93, 4) and (got[..., 3] == 255).all()
+        d = np.abs(got[..., :3].astype(int) - ref)
+        assert d.max() <= 3 and d.mean() < 0.5, (kw, d.max(), d.mean())
+    b = io.BytesIO()
+    Image.fromarray(img).save(b, "JPEG", progressive=True)
+    with pytest.raises(RuntimeError):  # progressive (SOF2) is refused, by name, not mis-decoded
+        frontend.decode_image(b.getvalue())
+
+
+def test_truncated_jpeg_and_garbage_rejected(ptlib):
     with pytest.raises(RuntimeError):
         frontend.decode_image(b"\xff\xd8\xff\xe0" + b"\0" * 32)
     with pytest.raises(RuntimeError):
