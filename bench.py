@@ -254,8 +254,10 @@ def cpu_baseline(packed, rp, gpu_accum, gpu_ids, seconds_hint: float) -> dict:
 # --------------------------------------------------------------------------- one workload
 
 def run_workload(be, name: str, steps: int, warmup: int, world: int, rank: int, split: str, spp_override: int,
-                 kernel_timing: bool, baseline_seconds: float, dist) -> dict | None:
-    """Render `name` steps times on every rank; returns rank 0's result dict (None elsewhere)."""
+                 kernel_timing: bool, baseline_seconds: float, dist, collectives: bool | None = None) -> dict | None:
+    """Render `name` steps times on every rank; returns rank 0's result dict (None elsewhere).  `collectives`: run the
+    reduce / barrier / all-reduce legs (default: whenever world > 1; a one-GPU box forces them on a one-rank group to
+    exercise the RCCL path, PT_BENCH_FORCE_COLLECTIVES=1)."""
     import numpy as np
     import torch
     from pathtracer_amd import abi, scenes
@@ -280,18 +282,20 @@ def run_workload(be, name: str, steps: int, warmup: int, world: int, rank: int, 
     pixels = width * height
     be.alloc(pixels)
     stats = abi.Stats()
+    if collectives is None:
+        collectives = world > 1
 
     def step(flags: int = 0, want_ids: bool = False, collective: bool = True):
         rp.flags = flags
         be.render(rp, stats, want_ids)
-        if world > 1 and collective:
+        if collectives and collective:
             be.reduce(dist)
         if rank == 0:
             be.resolve()
 
     def fence():
         be.sync()
-        if world > 1:
+        if collectives:
             dist.barrier()
         be.sync()
 
@@ -317,11 +321,11 @@ def run_workload(be, name: str, steps: int, warmup: int, world: int, rank: int, 
         render_ms += stats.render_ms
     fence()
     elapsed = time.perf_counter() - t0
-    reduce_ms = be.reduce_ms() if world > 1 else 0.0
+    reduce_ms = be.reduce_ms() if collectives else 0.0
     progress(f"{name}: {steps} timed step(s) in {elapsed:.2f} s")
 
     tot = torch.tensor([elapsed, float(rays), float(paths)], dtype=torch.float64, device=be.tensor_device)
-    if world > 1:
+    if collectives:
         mx = tot.clone()
         dist.all_reduce(mx, op=dist.ReduceOp.MAX)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
@@ -335,7 +339,7 @@ def run_workload(be, name: str, steps: int, warmup: int, world: int, rank: int, 
         step(want_ids=True, collective=False)
         frame = be.host_frame()
     last = stats.as_dict()
-    if world > 1:
+    if collectives:
         dist.barrier()
     if rank != 0:
         return None
@@ -352,7 +356,7 @@ def run_workload(be, name: str, steps: int, warmup: int, world: int, rank: int, 
                    "rays_per_step_per_gpu": int(stats.rays), "paths_per_step_per_gpu": int(stats.paths)},
         "counters": {k: int(last[k]) for k in COUNTERS},
     }
-    if world > 1:
+    if collectives:
         out["reduce_ms_per_step"] = reduce_ms / max(steps, 1)
     if last["rays"]:
         out["ray_mix"] = {"closest_hit": last["rays_closest"] / last["rays"], "shadow_walked": last["rays_shadow_walked"] / last["rays"],
@@ -465,13 +469,17 @@ def main(argv=None, backend_factory=None) -> None:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
         sys.exit(2)
     be = backend_factory(local_rank) if backend_factory else HipBackend(local_rank)
-    if world > 1:
+    # A one-GPU box cannot run N > 1; PT_BENCH_FORCE_COLLECTIVES=1 runs the same reduce / barrier / all-reduce calls on a
+    # one-rank process group, so the RCCL leg of this script is executed by the GPU suite at least once.
+    collectives = world > 1 or os.environ.get("PT_BENCH_FORCE_COLLECTIVES") == "1"
+    if collectives:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         kw = {"device_id": be.dev} if be.dist_backend == "nccl" else {}
         dist.init_process_group(be.dist_backend, rank=rank, world_size=world, **kw)
 
     head = run_workload(be, args.workload, args.steps, args.warmup, world, rank, args.split, args.spp,
-                        not args.no_kernel_timing, 0.0 if args.no_cpu_baseline else 12.0, dist)
+                        not args.no_kernel_timing, 0.0 if args.no_cpu_baseline else 12.0, dist, collectives)
     fast = None
     if (world == 1 and head is not None and "_frame" in head and not args.no_fast_arith and backend_factory is None
             and not args.spp and os.environ.get("PT_ARITH") != "fast"):
@@ -513,7 +521,7 @@ def main(argv=None, backend_factory=None) -> None:
         if extras:
             out["configs"] = extras
         print(json.dumps(out))
-    if world > 1:
+    if collectives:
         dist.barrier()
         dist.destroy_process_group()
     be.close()

@@ -76,3 +76,20 @@ def test_bench_script_on_the_gpu_verifies_the_frame_it_times():
     (cube,) = j["configs"]
     assert cube["name"] == "cube512" and cube["frame_properties_ok"] is True and cube["cpu_baseline"]["gpu_band_bit_exact"] is True
     assert 0 < cube["roofline"]["frac"] <= 1
+
+
+@pytest.mark.gpu
+def test_bench_script_rccl_leg_on_a_one_rank_group():
+    """A one-GPU box cannot launch N > 1, so the script's RCCL calls (process group on the device, the accumulator reduce on
+    the render stream, barrier, the MAX / SUM all-reduces of the timing) run here on a one-rank `nccl` group; the reduced
+    frame of one rank is that rank's frame, so the committed cfg2 digest still has to match."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29655", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
+               PT_BENCH_FORCE_COLLECTIVES="1")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--configs", "none",
+                        "--no-cpu-baseline", "--no-fast-arith"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    (line,) = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    j = json.loads(line)
+    _check_contract(j, 1, 2, 1)
+    assert j["reduce_ms_per_step"] > 0  # the reduce ran on the device and was timed by events on the render stream
+    assert j["frame_verified"] is True and j["frame_properties_ok"] is True
