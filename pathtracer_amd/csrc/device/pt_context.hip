@@ -148,6 +148,7 @@ struct pt_ctx {
   uint32_t refill_thresh = 0;       // EXPERIMENT PT_EXTEND_REFILL: parked lanes that trigger a refill (0 = plain k_extend)
   uint32_t refill_chunk = 256;      // PT_REFILL_CHUNK
   uint32_t refill_blocks = 0;       // PT_REFILL_BLOCKS (0 = what is resident at once)
+  bool shadow_refill = true;        // PT_SHADOW_REFILL=0: lane refill in k_extend only
   uint32_t sort_rays = 0;           // EXPERIMENT PT_SORT_RAYS: 1 = origin-major key, 2 = octant-major (wavefront pipeline only)
   uint32_t sort_bits = 6;           // PT_SORT_BITS: origin cell bits per axis
   uint32_t sort_shadow = 0;         // PT_SORT_SHADOW: also re-order the shadow queue
@@ -385,6 +386,7 @@ extern "C" pt_ctx* pt_create(int device) {
   if (const char* e = std::getenv("PT_LDS_STACK")) ctx->lds_stack = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   if (const char* e = std::getenv("PT_EXTEND_REFILL")) ctx->refill_thresh = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   if (const char* e = std::getenv("PT_REFILL_CHUNK")) ctx->refill_chunk = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
+  if (const char* e = std::getenv("PT_SHADOW_REFILL")) ctx->shadow_refill = std::atoi(e) != 0;
   if (const char* e = std::getenv("PT_REFILL_BLOCKS")) ctx->refill_blocks = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   if (ctx->refill_thresh > 64) ctx->refill_thresh = 64;
   if (ctx->refill_chunk < 64) ctx->refill_chunk = 64;
@@ -713,6 +715,9 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
     trace_block = 256u;
   }
   const int pipeline = no_alloc ? 0 : ctx->pipeline;
+  // (Choosing the wavefront pipeline with lane refill per scene was measured and dropped: +7 % on the 4.7 M-triangle rocks at
+  // 16 spp, -2 % at the config's 484 spp, where k_shade's state traffic outweighs what the refill saves)
+  const uint32_t refill_thresh = ctx->refill_thresh, refill_chunk = ctx->refill_chunk;
   const bool split = pipeline == 1 && ctx->split_shadow && !sc.scene_in_lds && n_lights != 0;
   int rc = PT_OK;
   if (no_alloc) {
@@ -821,9 +826,9 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
             pt_dev_state sorted = st;
             sorted.queue[parity] = ctx->sort_queue_out;
             timed(PT_K_EXTEND, [&] { ptd::launch_extend(sc, sorted, parity, bound, trace_block, ctx->trace_blocks, stream); });
-          } else if (ctx->refill_thresh && !sc.scene_in_lds && trace_block == 256) {
+          } else if (refill_thresh && !sc.scene_in_lds && trace_block == 256) {
             timed(PT_K_EXTEND, [&] {
-              ptd::launch_extend_refill(sc, st, parity, bound, ctx->refill_blocks, ctx->refill_chunk, ctx->refill_thresh, stream);
+              ptd::launch_extend_refill(sc, st, parity, bound, ctx->refill_blocks, refill_chunk, refill_thresh, stream);
             });
           } else {
             timed(PT_K_EXTEND, [&] { ptd::launch_extend(sc, st, parity, bound, trace_block, ctx->trace_blocks, stream); });
@@ -842,6 +847,10 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
             pt_dev_state sorted = st;
             sorted.queue_shadow = ctx->sort_shadow_out;
             timed(PT_K_SHADOW, [&] { ptd::launch_shadow(sc, f, sorted, bound, trace_block, ctx->trace_blocks, stream); });
+          } else if (split && refill_thresh && sc.all_opaque && !sc.scene_in_lds && trace_block == 256 && ctx->shadow_refill) {
+            timed(PT_K_SHADOW, [&] {
+              ptd::launch_shadow_refill(sc, f, st, bound, ctx->refill_blocks, refill_chunk, refill_thresh, stream);
+            });
           } else if (split) timed(PT_K_SHADOW, [&] { ptd::launch_shadow(sc, f, st, bound, trace_block, ctx->trace_blocks, stream); });
           if (compact) parity ^= 1u;
         }

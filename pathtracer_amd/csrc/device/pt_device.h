@@ -95,6 +95,8 @@ void launch_shadow(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_s
 void launch_paths(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity, uint32_t cnt_in,
                   uint32_t cnt_out, uint32_t cnt_zero, uint32_t max_entries, uint32_t block, uint32_t max_blocks,
                   uint32_t max_vertices, uint32_t xcd_chunk, hipStream_t s);
+void launch_shadow_refill(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t max_entries, uint32_t blocks,
+                          uint32_t chunk, uint32_t thresh, hipStream_t s);
 void launch_extend_refill(const pt_dev_scene& sc, const pt_dev_state& st, uint32_t parity, uint32_t max_entries, uint32_t blocks,
                           uint32_t chunk, uint32_t thresh, hipStream_t s);
 // experiment: ray re-ordering (pt_sort.hip)

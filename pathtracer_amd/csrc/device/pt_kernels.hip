@@ -880,7 +880,10 @@ __device__ __forceinline__ bool trav_step(const Tracer& tr, TravState& s, uint32
 // traversal has ended parks until `thresh` lanes are parked, then all of them store their hit and take the next
 // entries of the stream. The wave's trips are then filled with ~64 - thresh/2 rays instead of the 15 of 64 that a
 // wave of fixed membership averages on these scenes (its slowest ray sets its trip count). Per ray nothing changes.
-__global__ __launch_bounds__(256) void k_extend_refill(pt_dev_scene sc, pt_dev_state st, uint32_t parity, uint32_t chunk, uint32_t thresh) {
+#ifndef PT_EXTEND_REFILL_MIN_WAVES
+#define PT_EXTEND_REFILL_MIN_WAVES 1
+#endif
+__global__ __launch_bounds__(256, PT_EXTEND_REFILL_MIN_WAVES) void k_extend_refill(pt_dev_scene sc, pt_dev_state st, uint32_t parity, uint32_t chunk, uint32_t thresh) {
   extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
   const uint32_t n = st.counters[PT_CNT_QUEUE0 + parity];
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1421,6 +1424,119 @@ __global__ __launch_bounds__(256, ALL_OPAQUE ? PT_SHADOW_MIN_WAVES_OPAQUE : PT_S
   flush_tally(walks, st, PT_K_SHADOW);
 }
 
+// k_shadow for all-opaque scenes in global memory as persistent waves with LANE REFILL (see k_extend_refill): the any-hit
+// walks end after very different trip counts, so a wave of fixed membership idles most lanes. Here a lane whose walk has
+// ended parks; once `thresh` lanes are parked they book their sample (same expressions, same order as k_shadow), go on to
+// the slot's next light or finish the slot and take the next entry of the wave's stream. Per slot nothing changes.
+#ifndef PT_SHADOW_REFILL_MIN_WAVES
+#define PT_SHADOW_REFILL_MIN_WAVES 1
+#endif
+__global__ __launch_bounds__(256, PT_SHADOW_REFILL_MIN_WAVES) void k_shadow_refill(pt_dev_scene sc, pt_dev_frame f, pt_dev_state st, uint32_t chunk, uint32_t thresh) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
+  const uint32_t n = st.counters[PT_CNT_SHADOW];
+  Tally walks;
+  const uint32_t n_lights = sc.directional_light_count + sc.point_light_count + (f.pc.emissive_triangle_count ? 1u : 0u);
+  const vec3 bg_linear = mk(f.bg_linear[0], f.bg_linear[1], f.bg_linear[2]);
+  const size_t ss = st.slot_stride;
+  const Tracer tr = make_tracer<false>(sc, lds_dyn);
+  const uint32_t waves_total = gridDim.x * (blockDim.x >> 6);
+  const uint32_t wave_gid = blockIdx.x * (blockDim.x >> 6) + wave_id();
+  auto queue_index = [&](uint32_t v) { return ((v / chunk) * waves_total + wave_gid) * chunk + v % chunk; };
+  uint32_t vnext = 0;  // wave-uniform
+  bool live = false, has_slot = false, pending = false;
+  uint32_t slot = 0, j = 0;
+  vec3 punctual = splat(0.0f), area_light = splat(0.0f);
+  TravState s{};
+  uint32_t deep[kDeepLevels];
+  bool exhausted = queue_index(0) >= n;
+  for (;;) {
+    const bool want = !live && (has_slot || !exhausted);
+    const uint32_t n_want = static_cast<uint32_t>(__popcll(__ballot(want)));
+    const bool any_live = __ballot(live) != 0;
+    if (n_want >= thresh || (!any_live && n_want != 0)) {
+      if (want && pending) {  // a walk has ended: main.comp:445-455 / :485-498 for an all-opaque scene
+        pending = false;
+        if (s.h.tri == kNoHit) {  // transparency 1; the distance test needs a hit, so it cannot hold
+          const float4* r = st.req + (static_cast<size_t>(j) * 4u) * ss + slot;
+          const float4 r1 = r[ss], r2 = r[2 * ss], r3 = r[3 * ss];
+          const float transparency = 1.0f;
+          walks.taps += fbits(r3.z);
+          const vec3 c = xyz(r1) * transparency * xyz(r2) * r2.w / r3.x;
+          if (f.pc.emissive_triangle_count && j + 1 == n_lights) area_light = c;
+          else punctual = punctual + c;
+        }
+        ++j;
+      }
+      for (int pass = 0; pass < 2; ++pass) {
+        if (want && has_slot && !live) {
+          while (j < n_lights) {  // the slot's next light sample
+            const float4* r = st.req + (static_cast<size_t>(j) * 4u) * ss + slot;
+            const float4 r0 = r[0];
+            const vec3 l = xyz(r0);
+            if (f.pc.emissive_triangle_count && j + 1 == n_lights) {  // the emitter-first shortcut
+              const float4 r3 = r[3 * ss];
+              Hit sh{kInfinity, 0.0f, 0.0f, kNoHit};
+              ++walks.tests;
+              ray_triangle<false>(tr, s.o, l, fbits(r3.y), sh);
+              if (sh.tri != kNoHit) {
+                ++walks.rays;
+                ++walks.paths;  // shortcut count (see shade_vertex)
+                ++j;
+                continue;
+              }
+            }
+            trav_begin(tr, s.o, l, s, walks);
+            live = true;
+            pending = true;
+            break;
+          }
+          if (!live) {  // every light is booked: the vertex's colour, as in k_shadow
+            const float4* h = st.pend + slot;
+            const float4 h0 = h[0], h1 = h[ss], h3 = h[3 * ss];
+            vec3 direct = xyz(h0);
+            direct = direct + punctual;
+            direct = direct + area_light;
+            const vec3 color = xyz(h3) + direct * h0.w * xyz(h1);
+            if (fbits(h1.w) & 1u) {
+              float4 acc = st.accum[slot];
+              finish_sample(color, xyz(h[4 * ss]), bg_linear, acc, walks);
+              st.accum[slot] = acc;
+            } else {
+              float4 pb = st.path_b[slot];
+              pb.x = color.x;
+              pb.y = color.y;
+              pb.z = color.z;
+              st.path_b[slot] = pb;
+            }
+            has_slot = false;
+          }
+        }
+        if (pass == 0 && !exhausted) {  // wave-uniform: lanes without a slot take the next entries of the stream
+          const bool need = want && !has_slot;
+          const uint64_t m = __ballot(need);
+          if (need) {
+            const uint32_t q = queue_index(vnext + mbcnt(m));
+            if (q < n) {
+              slot = st.queue_shadow[q];
+              s.o = xyz(st.pend[2 * ss + slot]);
+              j = 0;
+              punctual = splat(0.0f);
+              area_light = splat(0.0f);
+              has_slot = true;
+            }
+          }
+          vnext += static_cast<uint32_t>(__popcll(m));
+          exhausted = queue_index(vnext) >= n;
+        }
+      }
+    } else if (!any_live) {
+      break;
+    }
+    if (live) live = trav_step<true>(tr, s, deep, walks);
+  }
+  flush_tally(walks, st, PT_K_SHADOW);
+}
+
 #endif  // !PT_FAST_ARITH
 
 // The path kernel: every queued slot advances by up to `max_vertices` path vertices — extend,
@@ -1611,6 +1727,22 @@ void launch_shadow(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_s
   if (grid > max_blocks) grid = max_blocks;
   if (sc.all_opaque) hipLaunchKernelGGL(k_shadow<true>, dim3(grid), dim3(block), trace_lds_bytes(sc, block), s, sc, f, st);
   else hipLaunchKernelGGL(k_shadow<false>, dim3(grid), dim3(block), trace_lds_bytes(sc, block), s, sc, f, st);
+}
+
+void launch_shadow_refill(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t max_entries, uint32_t blocks,
+                          uint32_t chunk, uint32_t thresh, hipStream_t s) {
+  const uint32_t block = 256;
+  const size_t lds = trace_lds_bytes(sc, block);
+  if (!blocks) {
+    int per_cu = 0, cus = 0, dev = 0;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_shadow_refill, block, lds);
+    blocks = static_cast<uint32_t>(per_cu > 0 ? per_cu : 1) * static_cast<uint32_t>(cus > 0 ? cus : 256);
+  }
+  uint32_t grid = blocks_for(max_entries, block);
+  if (grid > blocks) grid = blocks;
+  hipLaunchKernelGGL(k_shadow_refill, dim3(grid), dim3(block), lds, s, sc, f, st, chunk, thresh);
 }
 
 void launch_shade(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity,
