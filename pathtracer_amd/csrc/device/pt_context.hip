@@ -162,6 +162,27 @@ struct pt_ctx {
   hipEvent_t poll_events[2] = {nullptr, nullptr};
   hipEvent_t ev_start = nullptr, ev_stop = nullptr;
   std::vector<hipEvent_t> kernel_events;
+
+  // Concurrent bands (path pipeline, PT_CONCURRENT_BANDS): every band of the frame has its own stream, poll events and pinned
+  // words, and bands 1.. their own per-slot state and queues (band 0 uses `state`). The streams are the library's own, created
+  // one after another, so that they land on different hardware queues (HIP deals streams to GPU_MAX_HW_QUEUES = 4 queues in
+  // creation order; a band on the caller's stream shared a queue with another band and the frame got slower, not faster);
+  // the caller's stream only forks and joins them.
+  struct Band {
+    pt_dev_state state{};
+    std::vector<DevBuf> bufs;
+    uint32_t slots = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t poll_events[2] = {nullptr, nullptr};
+    hipEvent_t done = nullptr;
+    uint32_t* host_counts = nullptr;
+  };
+  std::vector<Band> bands;
+  uint32_t concurrent_bands = 2;    // measured on cfg2: 2 bands -10 % frame time wherever tried; 3 and 4 the same when every band's stream
+                                    // has a hardware queue to itself and SLOWER than one band when two of them share one (which
+                                    // depends on what else the process has created: 4 bands gave 91 / 95 / 105 ms in three hosts); 6, 8 worse
+  uint32_t band_min_tiles = 4096;   // PT_BAND_MIN_TILES: fewer concurrent bands rather than bands below this many 8x8 tiles
+  hipEvent_t fork_event = nullptr;
 };
 
 namespace {
@@ -271,6 +292,49 @@ int validate_scene(pt_ctx* ctx, const pt_scene_desc* s, uint32_t* depth_out) {
     const pt_image& im = s->images[i];
     if (!im.width || !im.height || !im.rgba8 || im.width > 32768 || im.height > 32768)
       return fail(ctx, PT_ERR_INVALID, "scene: image %u is empty or too large", i);
+  }
+  return PT_OK;
+}
+
+// A frame rendered as n concurrent bands: a stream, two poll events, a join event and pinned words per band, and per-slot
+// state of `slots` slots (path pipeline: no shadow requests) for bands 1..n-1; created on first use and kept.
+int ensure_bands(pt_ctx* ctx, uint32_t n, uint32_t slots) {
+  if (ctx->bands.size() < n) ctx->bands.resize(n);
+  if (!ctx->fork_event) PT_HIP(ctx, hipEventCreateWithFlags(&ctx->fork_event, hipEventDisableTiming));
+  for (uint32_t b = 0; b < n; ++b)  // the streams first, back to back
+    if (!ctx->bands[b].stream) PT_HIP(ctx, hipStreamCreateWithFlags(&ctx->bands[b].stream, hipStreamNonBlocking));
+  for (uint32_t b = 0; b < n; ++b) {
+    pt_ctx::Band& band = ctx->bands[b];
+    if (!band.done) {
+      PT_HIP(ctx, hipEventCreate(&band.poll_events[0]));
+      PT_HIP(ctx, hipEventCreate(&band.poll_events[1]));
+      PT_HIP(ctx, hipEventCreateWithFlags(&band.done, hipEventDisableTiming));
+      PT_HIP(ctx, hipHostMalloc(reinterpret_cast<void**>(&band.host_counts), 64 + sizeof(unsigned long long) * PT_K_COUNT * PT_ST_WORDS,
+                                hipHostMallocDefault));
+    }
+    if (b == 0 || band.slots == slots) continue;
+    free_bufs(band.bufs);
+    band.slots = 0;
+    pt_dev_state& st = band.state;
+    st = pt_dev_state{};
+    int rc;
+#define ALLOC(field, count) \
+  if ((rc = dev_alloc(ctx, band.bufs, &field, (count))) != PT_OK) return rc
+    ALLOC(st.ray_o, slots);
+    ALLOC(st.ray_d, slots);
+    ALLOC(st.path_a, slots);
+    ALLOC(st.path_b, slots);
+    ALLOC(st.accum, slots);
+    ALLOC(st.primary_id, slots);
+    ALLOC(st.queue[0], slots);
+    ALLOC(st.queue[1], slots);
+    st.slot_stride = slots;
+    ALLOC(st.counters, PT_CNT_WORDS);
+    st.stat_rows = slots / 64 * 2 + 16;
+    ALLOC(st.stats, static_cast<size_t>(PT_K_COUNT) * st.stat_rows * PT_ST_WORDS);
+    ALLOC(st.stat_totals, static_cast<size_t>(PT_K_COUNT) * PT_ST_WORDS);
+#undef ALLOC
+    band.slots = slots;
   }
   return PT_OK;
 }
@@ -394,6 +458,11 @@ extern "C" pt_ctx* pt_create(int device) {
   if (const char* e = std::getenv("PT_SORT_BITS")) ctx->sort_bits = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   if (const char* e = std::getenv("PT_SORT_SHADOW")) ctx->sort_shadow = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   if (ctx->sort_bits < 1 || ctx->sort_bits > 9) ctx->sort_bits = 6;
+  if (const char* e = std::getenv("PT_CONCURRENT_BANDS")) ctx->concurrent_bands = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
+  if (const char* e = std::getenv("PT_BAND_MIN_TILES")) ctx->band_min_tiles = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
+  if (ctx->band_min_tiles < 1) ctx->band_min_tiles = 1;
+  if (ctx->concurrent_bands < 1) ctx->concurrent_bands = 1;
+  if (ctx->concurrent_bands > 8) ctx->concurrent_bands = 8;
   if (const char* e = std::getenv("PT_BAND_SLOTS")) ctx->band_slots = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   bool ok = hipSetDevice(device) == hipSuccess &&
             hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) == hipSuccess &&
@@ -455,6 +524,16 @@ extern "C" void pt_destroy(pt_ctx* ctx) {
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   free_bufs(ctx->scene_bufs);
   free_bufs(ctx->state_bufs);
+  for (pt_ctx::Band& band : ctx->bands) {
+    if (band.stream) (void)hipStreamSynchronize(band.stream);
+    free_bufs(band.bufs);
+    if (band.host_counts) (void)hipHostFree(band.host_counts);
+    for (hipEvent_t e : band.poll_events)
+      if (e) (void)hipEventDestroy(e);
+    if (band.done) (void)hipEventDestroy(band.done);
+    if (band.stream) (void)hipStreamDestroy(band.stream);
+  }
+  if (ctx->fork_event) (void)hipEventDestroy(ctx->fork_event);
   if (ctx->host_counts) (void)hipHostFree(ctx->host_counts);
   for (hipEvent_t e : ctx->poll_events)
     if (e) (void)hipEventDestroy(e);
@@ -715,6 +794,20 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
     trace_block = 256u;
   }
   const int pipeline = no_alloc ? 0 : ctx->pipeline;
+  // Concurrent bands (path pipeline): the frame is cut into `conc` bands of tiles, each with its own state, queues and stream,
+  // and their launches are enqueued alternately. Every k_paths launch ends with a tail in which most of the GPU idles while the
+  // last waves finish their vertices (a 1080p launch is only ~5 rounds of resident waves); the other band's launch fills it.
+  // Per slot nothing changes, so the frame is the same to the bit.
+  // Per-kernel timing (PT_FLAG_TIME_KERNELS) renders the bands one after another: the duration of a launch that shares the GPU
+  // with another band's launch says nothing about the kernel.
+  const bool time_kernels = (p->flags & PT_FLAG_TIME_KERNELS) != 0;
+  uint32_t conc = 1;
+  if (pipeline == 0 && !no_alloc && !time_kernels && ctx->concurrent_bands > 1 && band_slots == total_slots) {
+    const uint32_t tiles = total_slots / 64;
+    conc = ctx->concurrent_bands;
+    while (conc > 1 && tiles / conc < ctx->band_min_tiles) --conc;  // a band should still fill the GPU (4096 waves resident) on its own
+    if (conc > 1) band_slots = ((tiles + conc - 1) / conc) * 64u;
+  }
   // (Choosing the wavefront pipeline with lane refill per scene was measured and dropped: +7 % on the 4.7 M-triangle rocks at
   // 16 spp, -2 % at the config's 484 spp, where k_shade's state traffic outweighs what the refill saves)
   const uint32_t refill_thresh = ctx->refill_thresh, refill_chunk = ctx->refill_chunk;
@@ -733,30 +826,31 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
   } else {
     rc = ensure_state(ctx, band_slots, split ? n_lights : 0u, pixels);
     if (rc != PT_OK) return rc;
+    if (conc > 1 && (rc = ensure_bands(ctx, conc, band_slots)) != PT_OK) return rc;
     if (!accum_dev) accum_dev = ctx->accum_out;
     if (!primary_dev) primary_dev = ctx->primary_out;
   }
   const pt_dev_state& st = no_alloc ? ctx->scratch_state : ctx->state;
-  const bool time_kernels = (p->flags & PT_FLAG_TIME_KERNELS) != 0;
   size_t ev_used = 0;
   std::vector<std::pair<size_t, int>> ev_kind;  // index of the start event, kernel id
   uint64_t launches[PT_K_COUNT + 1] = {0, 0, 0, 0, 0};
 
-  auto timed = [&](int kind, auto&& launch) {
+  auto timed_on = [&](hipStream_t on, int kind, auto&& launch) {
     ++launches[kind];
     if (time_kernels) {
       hipEvent_t a = next_kernel_event(ctx, ev_used);
       hipEvent_t b = next_kernel_event(ctx, ev_used);
       if (a && b) {
         ev_kind.emplace_back(ev_used - 2, kind);
-        (void)hipEventRecord(a, stream);
+        (void)hipEventRecord(a, on);
         launch();
-        (void)hipEventRecord(b, stream);
+        (void)hipEventRecord(b, on);
         return;
       }
     }
     launch();
   };
+  auto timed = [&](int kind, auto&& launch) { timed_on(stream, kind, launch); };
 
   PT_HIP(ctx, hipMemsetAsync(st.stats, 0, static_cast<size_t>(PT_K_COUNT) * st.stat_rows * PT_ST_WORDS * sizeof(unsigned long long), stream));
   PT_HIP(ctx, hipEventRecord(ctx->ev_start, stream));
@@ -765,6 +859,81 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
   const uint64_t max_iters = static_cast<uint64_t>(f.sample_end - f.sample_begin) * 12ull + 2ull;
   constexpr uint32_t kBatch = 16;
   uint64_t iter_total = 0;
+  if (conc > 1) {
+    struct Run {
+      const pt_dev_state* st;
+      hipStream_t s;
+      hipEvent_t* pe;
+      hipEvent_t done;
+      uint32_t* hc;
+      pt_dev_frame f;
+      uint32_t bound, k;
+      uint64_t vertices;
+      int poll;
+      bool have_prev, drained;
+    };
+    std::vector<Run> runs;
+    PT_HIP(ctx, hipEventRecord(ctx->fork_event, stream));
+    for (uint32_t c = 0; c < conc && c * band_slots < total_slots; ++c) {
+      pt_ctx::Band* band = &ctx->bands[c];
+      Run r{};
+      r.st = c ? &band->state : &ctx->state;
+      r.s = band->stream;
+      r.pe = band->poll_events;
+      r.done = band->done;
+      r.hc = band->host_counts;
+      r.f = f;
+      r.f.slot_base = c * band_slots;
+      r.f.slot_count = (total_slots - r.f.slot_base < band_slots) ? total_slots - r.f.slot_base : band_slots;
+      r.bound = r.f.slot_count;
+      r.drained = (f.sample_begin == f.sample_end);
+      PT_HIP(ctx, hipStreamWaitEvent(r.s, ctx->fork_event, 0));
+      if (c) PT_HIP(ctx, hipMemsetAsync(r.st->stats, 0, static_cast<size_t>(PT_K_COUNT) * r.st->stat_rows * PT_ST_WORDS * sizeof(unsigned long long), r.s));
+      PT_HIP(ctx, hipMemsetAsync(r.st->counters, 0, PT_CNT_WORDS * sizeof(uint32_t), r.s));
+      ptd::launch_init(r.f, *r.st, r.s);
+      runs.push_back(r);
+    }
+    for (bool any = true; any;) {
+      any = false;
+      for (Run& r : runs) {
+        if (r.drained || r.vertices >= max_iters) continue;
+        any = true;
+        timed_on(r.s, PT_K_PATHS, [&] {
+          (ctx->fast_arith ? ptd_fast::launch_paths : ptd::launch_paths)(
+              sc, r.f, *r.st, r.k & 1u, PT_CNT_QUEUE0 + r.k % 3u, PT_CNT_QUEUE0 + (r.k + 1u) % 3u, PT_CNT_QUEUE0 + (r.k + 2u) % 3u, r.bound,
+              trace_block < ctx->paths_block_threads ? trace_block : ctx->paths_block_threads, ctx->paths_blocks, ctx->paths_vertices,
+              sc.scene_in_lds ? 0u : ctx->xcd_chunk, r.s);
+        });
+        PT_HIP(ctx, hipGetLastError());
+        // the band's live count after this launch, looked at one launch later (the GPU never waits for the host)
+        PT_HIP(ctx, hipMemcpyAsync(&r.hc[r.poll], r.st->counters + PT_CNT_QUEUE0 + (r.k + 1u) % 3u, sizeof(uint32_t), hipMemcpyDeviceToHost, r.s));
+        PT_HIP(ctx, hipEventRecord(r.pe[r.poll], r.s));
+        if (r.have_prev) {
+          PT_HIP(ctx, hipEventSynchronize(r.pe[r.poll ^ 1]));
+          const uint32_t live = r.hc[r.poll ^ 1];
+          if (ctx->log_launches) std::fprintf(stderr, "[pt] band %u: %u slots live after the launch before last\n", r.f.slot_base, live);
+          if (live == 0) r.drained = true;
+          else if (live < r.bound) r.bound = live;
+        }
+        r.have_prev = true;
+        r.poll ^= 1;
+        ++r.k;
+        r.vertices += ctx->paths_vertices;
+      }
+    }
+    for (Run& r : runs) {
+      if (!r.drained) {
+        PT_HIP(ctx, hipEventSynchronize(r.pe[r.poll ^ 1]));
+        if (r.hc[r.poll ^ 1] != 0)
+          return fail(ctx, PT_ERR_DEVICE, "render loop did not drain after %u launches", r.k);
+      }
+      ptd::launch_finalize(r.f, *r.st, accum_dev, primary_dev, r.s);
+      if (stats_out) ptd::launch_sum_stats(*r.st, r.s);
+      PT_HIP(ctx, hipEventRecord(r.done, r.s));  // join: the caller's stream goes on after every band
+      PT_HIP(ctx, hipStreamWaitEvent(stream, r.done, 0));
+      if (r.k > iter_total) iter_total = r.k;
+    }
+  } else
   for (uint32_t base = 0; base < total_slots; base += band_slots) {
     f.slot_base = base;
     f.slot_count = (total_slots - base < band_slots) ? total_slots - base : band_slots;
@@ -877,7 +1046,7 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
     iter_total += iter;
   }
   const uint64_t iter = iter_total;
-  if (stats_out) ptd::launch_sum_stats(st, stream);
+  if (stats_out && conc == 1) ptd::launch_sum_stats(st, stream);
   PT_HIP(ctx, hipEventRecord(ctx->ev_stop, stream));
   PT_HIP(ctx, hipGetLastError());
   PT_HIP(ctx, hipStreamSynchronize(stream));
@@ -889,6 +1058,14 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
     PT_HIP(ctx, hipMemcpyAsync(pinned, st.stat_totals, sizeof(h), hipMemcpyDeviceToHost, stream));
     PT_HIP(ctx, hipStreamSynchronize(stream));
     std::memcpy(&h[0][0], pinned, sizeof(h));
+    for (uint32_t c = 1; c < conc && c * band_slots < total_slots; ++c) {  // the other concurrent bands' totals
+      pt_ctx::Band& band = ctx->bands[c];
+      unsigned long long* bp = reinterpret_cast<unsigned long long*>(reinterpret_cast<unsigned char*>(band.host_counts) + 64);
+      PT_HIP(ctx, hipMemcpyAsync(bp, band.state.stat_totals, sizeof(h), hipMemcpyDeviceToHost, stream));
+      PT_HIP(ctx, hipStreamSynchronize(stream));
+      for (int k = 0; k < PT_K_COUNT; ++k)
+        for (int w = 0; w < PT_ST_WORDS; ++w) h[k][w] += bp[k * PT_ST_WORDS + w];
+    }
     std::memset(stats_out, 0, sizeof(*stats_out));
     auto total = [&](int w) { return h[PT_K_INIT][w] + h[PT_K_EXTEND][w] + h[PT_K_SHADE][w] + h[PT_K_SHADOW][w]; };
     // (the shadow slice's PATHS word counts the shortcut-decided shadow rays, not paths)
@@ -922,6 +1099,7 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
     for (auto& [idx, kind] : ev_kind) {
       float k = 0.0f;
       if (hipEventElapsedTime(&k, ctx->kernel_events[idx], ctx->kernel_events[idx + 1]) == hipSuccess) per[kind]->ms += k;
+      if (ctx->log_launches) std::fprintf(stderr, "[pt] launch %zu: kernel %d, %.3f ms\n", idx / 2, kind, k);
     }
   }
   return PT_OK;

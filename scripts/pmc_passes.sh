@@ -6,6 +6,7 @@ set -u
 out=$1; shift
 mkdir -p "$out"
 export TMPDIR=/tmp
+export PT_CONCURRENT_BANDS=1  # per-launch figures of whole-frame launches, as in the profiled step of bench.py
 i=0
 while read -r set; do
   [ -z "$set" ] && continue

@@ -131,7 +131,10 @@ def test_rank_split_matches_oracle_per_rank(renderer, oracle):
                                  {"PT_PIPELINE": "wavefront", "PT_EXTEND_REFILL": "16", "PT_REFILL_CHUNK": "64", "PT_LDS_STACK": "4"},
                                  {"PT_PIPELINE": "wavefront", "PT_EXTEND_REFILL": "16", "PT_SHADOW_REFILL": "0"},
                                  {"PT_PIPELINE": "wavefront", "PT_EXTEND_REFILL": "40", "PT_REFILL_CHUNK": "128", "PT_TAIL_ENTRIES": "0"},
-                                 {"PT_PIPELINE": "wavefront", "PT_SORT_RAYS": "1", "PT_SORT_SHADOW": "1"}])
+                                 {"PT_PIPELINE": "wavefront", "PT_SORT_RAYS": "1", "PT_SORT_SHADOW": "1"},
+                                 {"PT_CONCURRENT_BANDS": "3", "PT_BAND_MIN_TILES": "1"},
+                                 {"PT_CONCURRENT_BANDS": "7", "PT_BAND_MIN_TILES": "1", "PT_PATHS_VERTICES": "5"},
+                                 {"PT_CONCURRENT_BANDS": "1"}])
 def test_alternative_pipelines_give_the_same_bits(oracle, monkeypatch, env):
     """The wavefront pipeline (k_extend + k_shade, fused or with the split k_shadow, lazy or per-iteration
     compaction, with or without the k_paths tail) and other k_paths launch shapes: same results as the default."""
