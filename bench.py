@@ -273,7 +273,9 @@ def run_workload(be, name: str, steps: int, warmup: int, world: int, rank: int, 
     packed = be.pack(scene)
     build_s = time.perf_counter() - t0
     progress(f"{name}: {len(packed.nodes)} nodes, depth {packed.bvh_max_depth}; uploading")
+    t0 = time.perf_counter()
     be.upload(packed)
+    upload_s = time.perf_counter() - t0  # validation + re-layout into pair records + H2D, once per scene (never per frame)
     bg = BG.get(name, (0.239, 0.239, 0.239))
     if split == "strata":
         rp = packed.render_params(be.lib, width, height, spp, bg, SEED, rank, world)
@@ -352,7 +354,7 @@ def run_workload(be, name: str, steps: int, warmup: int, world: int, rank: int, 
         "device_ms_per_step": render_ms / max(steps, 1),
         "config": {"workload": desc, "name": name, "resolution": [width, height], "sample_count": spp, "effective_spp": eff,
                    "triangles": int(scene.triangles.shape[0]), "bvh_nodes": int(len(packed.nodes)),
-                   "bvh_depth": int(packed.bvh_max_depth), "host_bvh_build_s": build_s, "iterations": int(last["iterations"]),
+                   "bvh_depth": int(packed.bvh_max_depth), "host_bvh_build_s": build_s, "scene_upload_s": upload_s, "iterations": int(last["iterations"]),
                    "rays_per_step_per_gpu": int(stats.rays), "paths_per_step_per_gpu": int(stats.paths)},
         "counters": {k: int(last[k]) for k in COUNTERS},
     }
