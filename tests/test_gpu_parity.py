@@ -172,7 +172,7 @@ def test_render_before_upload_fails_loudly():
 def test_cfg2_full_size_properties(renderer, oracle, monkeypatch):
     """BASELINE configs[1] at its full size (1920x1080, sample_count 128 -> 121 strata): size-independent
     properties on the whole frame, a band of rows against the oracle at the full sample count, and the same
-    frame from the wavefront pipeline."""
+    frame from the wavefront pipeline and from other band counts."""
     import hashlib
     packed = renderer.pack(scenes.cornell_scene())
     renderer.upload(packed)
@@ -201,7 +201,9 @@ def test_cfg2_full_size_properties(renderer, oracle, monkeypatch):
     assert hashlib.sha256(accum2.tobytes() + ids2.tobytes()).hexdigest() == digest
     # the wavefront pipeline at full size: queue striding (more entries than the shade grid), compaction on
     # every iteration (the shape that once lost slots to a race in the block-level append) and the default
-    for env in ({"PT_PIPELINE": "wavefront", "PT_COMPACT_EVERY": "1", "PT_TAIL_ENTRIES": "0"}, {"PT_PIPELINE": "wavefront"}):
+    # ... and the path pipeline with the frame as one band and as three (the default above: two concurrent bands)
+    for env in ({"PT_PIPELINE": "wavefront", "PT_COMPACT_EVERY": "1", "PT_TAIL_ENTRIES": "0"}, {"PT_PIPELINE": "wavefront"},
+                {"PT_CONCURRENT_BANDS": "1"}, {"PT_CONCURRENT_BANDS": "3"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         r2 = Renderer(0)
