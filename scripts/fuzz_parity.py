@@ -1,0 +1,48 @@
+"""One-off parity campaign, wider than the test suite's fuzz: N seeded random scenes (every switch combination) on the GPU
+against the oracle, bit for bit (accumulators, ids, rgba8, work counters), under several launch shapes.
+Usage: python scripts/fuzz_parity.py [first_seed] [count]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np  # noqa: E402
+import torch  # noqa: F401,E402
+import oracle_lib  # noqa: E402
+from pathtracer_amd import scenes  # noqa: E402
+from pathtracer_amd.renderer import Renderer  # noqa: E402
+
+COUNTERS = ["paths", "rays", "node_visits", "tri_tests", "hits_shaded", "texture_taps", "shaded_vertices", "nan_samples"]
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
+count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+ENVS = [{}, {"PT_CONCURRENT_BANDS": "3", "PT_BAND_MIN_TILES": "1"}, {"PT_PIPELINE": "wavefront", "PT_EXTEND_REFILL": "16", "PT_REFILL_CHUNK": "64"},
+        {"PT_PIPELINE": "wavefront", "PT_TAIL_ENTRIES": "0"}, {"PT_LDS_SCENE_BYTES": "0", "PT_CONCURRENT_BANDS": "2", "PT_BAND_MIN_TILES": "2"}]
+oracle = oracle_lib.load()
+bad = 0
+for e_i, env in enumerate(ENVS):
+    for k in ("PT_CONCURRENT_BANDS", "PT_BAND_MIN_TILES", "PT_PIPELINE", "PT_EXTEND_REFILL", "PT_REFILL_CHUNK", "PT_TAIL_ENTRIES", "PT_LDS_SCENE_BYTES"):
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    r = Renderer(0)
+    n = count if e_i == 0 else max(count // 4, 1)
+    for i in range(n):
+        seed = first + i
+        sw = (seed & 1, (seed >> 1) & 1, (seed >> 2) & 1)
+        scene = scenes.random_scene(seed, with_textures=bool(sw[0]), with_punctual=bool(sw[1]), with_alpha=bool(sw[2]))
+        w, h, spp = (64, 40, 9) if i % 5 else (96, 56, 16)
+        packed = r.pack(scene)
+        r.upload(packed)
+        rp = packed.render_params(r.lib, w, h, spp, (0.239, 0.239, 0.239), seed)
+        rgba, accum, ids, st = r.render_params(rp)
+        o_rgba, o_accum, o_ids, _ = oracle_lib.render(oracle, packed, rp, threads=16)
+        o_st = oracle_lib.render(oracle, packed, rp, threads=16, flags=oracle_lib.GPU_MIRROR)[3]
+        ok = ((ids == o_ids).all() and (accum.view(np.uint32) == o_accum.view(np.uint32)).all() and (rgba == o_rgba).all()
+              and all(st[k] == o_st[k] for k in COUNTERS))
+        if not ok:
+            bad += 1
+            print(f"MISMATCH env {env} seed {seed} switches {sw} {w}x{h} spp {spp}", flush=True)
+    print(f"env {env}: {n} scenes done, mismatches so far {bad}", flush=True)
+    r.close()
+print("FUZZ", "FAILED" if bad else "ok", flush=True)
+sys.exit(1 if bad else 0)
