@@ -55,8 +55,8 @@ WORKLOADS = {
     "cornell_tiny": ("cornell_scene", {}, 96, 54, 16, "test-sized Cornell box (tests/test_bench_script.py); not a bench line"),
 }
 BG = {"atrium1080": (0.5, 0.7, 1.0), "rocks1080": (0.5, 0.7, 1.0), "soup1080": (0.5, 0.7, 1.0)}  # sky; others: README default
-EXTRA_DEFAULT = "cube512,atrium1080,rocks1080"
-EXTRA_STEPS = {"cube512": 20, "atrium1080": 2, "rocks1080": 2}
+EXTRA_DEFAULT = "cube512,atrium1080,rocks1080,cornell4k"
+EXTRA_STEPS = {"cube512": 20, "atrium1080": 2, "rocks1080": 2, "cornell4k": 1}
 SEED = 0x5EED0000
 COUNTERS = ("paths", "rays", "rays_closest", "rays_shadow_walked", "rays_shadow_shortcut", "node_visits", "tri_tests",
             "hits_shaded", "texture_taps", "shaded_vertices", "nan_samples")
