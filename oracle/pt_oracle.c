@@ -561,18 +561,30 @@ static void get_material_data(shctx* c, uint32_t mat_idx, float tu, float tv, v3
 static uint64_t* g_visit_hist = NULL;
 void orc_set_visit_histogram(uint64_t* per_node_counts) { g_visit_hist = per_node_counts; }
 
+/* Diagnostic (off unless a script sets it; one thread only): per traversal, the number of loop trips (inner visits + leaves
+ * entered) and whether it was an any-hit walk, appended to a caller-owned log. Sizes lane-occupancy models of the kernels. */
+static uint32_t* g_trip_log = NULL;
+static size_t g_trip_cap = 0, g_trip_len = 0;
+void orc_set_trip_log(uint32_t* log, size_t capacity) { g_trip_log = log; g_trip_cap = capacity; g_trip_len = 0; }
+size_t orc_trip_log_length(void) { return g_trip_len; }
+
 static void ray_scene_intersect_ex(shctx* c, const ray_t* ray, isect_t* info, int any_hit) {
   ++c->st.rays;
   const pt_packed_bvh_node* nodes = c->sc->bvh_nodes;
   uint32_t* stack = c->stack;
   uint32_t top = 0;
+  uint32_t trips = 0;
   stack[top++] = 0;
   while (top != 0) {
     const pt_packed_bvh_node* node = &nodes[stack[--top]];
+    ++trips;
     if (node->triangle_count > 0) {
       for (uint32_t i = 0; i < node->triangle_count; ++i) {
         ray_triangle_intersect(c, ray, node->left_or_begin + i, info);
-        if (any_hit && info->tri_idx != ORC_NO_HIT) return;
+        if (any_hit && info->tri_idx != ORC_NO_HIT) {
+          if (g_trip_log && g_trip_len < g_trip_cap) g_trip_log[g_trip_len++] = trips | 0x80000000u;
+          return;
+        }
       }
     } else {
       ++c->st.node_visits;
@@ -599,6 +611,7 @@ static void ray_scene_intersect_ex(shctx* c, const ray_t* ray, isect_t* info, in
       }
     }
   }
+  if (g_trip_log && g_trip_len < g_trip_cap) g_trip_log[g_trip_len++] = trips | (any_hit ? 0x80000000u : 0u);
 }
 
 static void ray_scene_intersect(shctx* c, const ray_t* ray, isect_t* info) {
