@@ -236,6 +236,65 @@ __device__ __forceinline__ float4 fetch16(const float4* base, uint32_t index) {
   return base[index];
 }
 
+// Keep 16-byte fetches from global memory WHOLE. Left to itself the compiler narrows a float4 load to the words that are used
+// and re-splits it into overlapping 8-byte loads that land in aligned register pairs for the packed arithmetic: a triangle's
+// three vertices became five loads (4 x dwordx2 + dwordx3). On the scenes read from global memory the kernel is bound by the
+// rate of divergent lane loads, not by VALU, so one dwordx4 per vertex and a few v_mov are the better trade. The empty asm
+// makes every quad a 128-bit register operand; it emits nothing and changes no value.
+#ifndef PT_PIN_TRI
+#define PT_PIN_TRI 1
+#endif
+#ifndef PT_PIN_INTERP
+#define PT_PIN_INTERP 0
+#endif
+#ifndef PT_PIN_MAT
+#define PT_PIN_MAT 0
+#endif
+#ifndef PT_PIN_EMIT
+#define PT_PIN_EMIT 0
+#endif
+#ifndef PT_PIN_ATTR
+#define PT_PIN_ATTR 1
+#endif
+typedef float pt_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 as_float4(pt_f4 v) { return make_float4(v.x, v.y, v.z, v.w); }
+template <bool IN_LDS, bool PIN = true>
+__device__ __forceinline__ void fetch16x3(const float4* base, uint32_t index, float4& a, float4& b, float4& c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (!IN_LDS && PIN) {
+    const pt_f4* p = reinterpret_cast<const pt_f4*>(base) + index;
+    pt_f4 x = p[0], y = p[1], z = p[2];
+    asm("" : "+v"(x), "+v"(y), "+v"(z));
+    a = as_float4(x);
+    b = as_float4(y);
+    c = as_float4(z);
+    return;
+  }
+#endif
+  a = fetch16<IN_LDS>(base, index);
+  b = fetch16<IN_LDS>(base, index + 1);
+  c = fetch16<IN_LDS>(base, index + 2);
+}
+template <bool IN_LDS, bool PIN = true>
+__device__ __forceinline__ void fetch16x4(const float4* base, uint32_t index, float4& a, float4& b, float4& c, float4& d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  if constexpr (!IN_LDS && PIN) {
+    const pt_f4* p = reinterpret_cast<const pt_f4*>(base) + index;
+    pt_f4 x = p[0], y = p[1], z = p[2], w = p[3];
+    asm("" : "+v"(x), "+v"(y), "+v"(z), "+v"(w));
+    a = as_float4(x);
+    b = as_float4(y);
+    c = as_float4(z);
+    d = as_float4(w);
+    return;
+  }
+#endif
+  a = fetch16<IN_LDS>(base, index);
+  b = fetch16<IN_LDS>(base, index + 1);
+  c = fetch16<IN_LDS>(base, index + 2);
+  d = fetch16<IN_LDS>(base, index + 3);
+}
+
 // (ref, cnt) of side 0/1 of pair record `rec`: one 8-byte fetch from the record's last quad
 template <bool IN_LDS>
 __device__ __forceinline__ uint2 fetch_child(const float4* pairs, uint32_t rec, uint32_t side) {
@@ -256,9 +315,11 @@ __device__ __forceinline__ uint2 fetch_child(const float4* pairs, uint32_t rec, 
 template <bool IN_LDS>
 __device__ __forceinline__ void ray_triangle(const Tracer& tr, vec3 o, vec3 d, uint32_t tri, Hit& h) {
 #pragma clang fp contract(off)
-  const vec3 p0 = xyz(fetch16<IN_LDS>(tr.tri_pos, 3 * tri));
-  const vec3 edge1 = sub_x(xyz(fetch16<IN_LDS>(tr.tri_pos, 3 * tri + 1)), p0);
-  const vec3 edge2 = sub_x(xyz(fetch16<IN_LDS>(tr.tri_pos, 3 * tri + 2)), p0);
+  float4 v0, v1, v2;
+  fetch16x3<IN_LDS, PT_PIN_TRI != 0>(tr.tri_pos, 3 * tri, v0, v1, v2);
+  const vec3 p0 = xyz(v0);
+  const vec3 edge1 = sub_x(xyz(v1), p0);
+  const vec3 edge2 = sub_x(xyz(v2), p0);
   const vec3 ray_cross_edge2 = cross_x(d, edge2);
   const float det = dot_x(edge1, ray_cross_edge2);
   if (__builtin_fabsf(det) < kEpsilon) return;
@@ -502,8 +563,8 @@ struct TriAttr {  // 64-byte attribute record: normals, uvs, material of one tri
 
 template <bool IN_LDS>
 __device__ __forceinline__ TriAttr load_attr(const float4* tri_attr, uint32_t tri) {
-  const float4 a = fetch16<IN_LDS>(tri_attr, 4 * tri), b = fetch16<IN_LDS>(tri_attr, 4 * tri + 1);
-  const float4 c = fetch16<IN_LDS>(tri_attr, 4 * tri + 2), e = fetch16<IN_LDS>(tri_attr, 4 * tri + 3);
+  float4 a, b, c, e;
+  fetch16x4<IN_LDS, PT_PIN_ATTR != 0>(tri_attr, 4 * tri, a, b, c, e);
   TriAttr r;
   r.n0 = mk(a.x, a.y, a.z);
   r.n1 = mk(a.w, b.x, b.y);
@@ -527,8 +588,8 @@ struct Material {  // main.comp:42-58
 
 template <bool IN_LDS>
 __device__ __forceinline__ Material load_material(const float4* mats, uint32_t idx) {
-  const float4 a = fetch16<IN_LDS>(mats, 4 * idx), b = fetch16<IN_LDS>(mats, 4 * idx + 1);
-  const float4 c = fetch16<IN_LDS>(mats, 4 * idx + 2), e = fetch16<IN_LDS>(mats, 4 * idx + 3);
+  float4 a, b, c, e;
+  fetch16x4<IN_LDS, PT_PIN_MAT != 0>(mats, 4 * idx, a, b, c, e);
   Material m;
   m.base_color = a;
   m.base_tex = static_cast<int>(fbits(b.x));
@@ -605,9 +666,8 @@ template <bool IN_LDS>
 __device__ __forceinline__ void interpolate_pos_uv(const ShadeData& sd, uint32_t tri, vec3 wuv, vec3& pos,
                                                    float& tu, float& tv, uint32_t& mat, vec3* normal, Tally& tally) {
   ++tally.hits;
-  const float4 q0 = fetch16<IN_LDS>(sd.tri_pos, 3 * tri);
-  const float4 q1 = fetch16<IN_LDS>(sd.tri_pos, 3 * tri + 1);
-  const float4 q2 = fetch16<IN_LDS>(sd.tri_pos, 3 * tri + 2);
+  float4 q0, q1, q2;
+  fetch16x3<IN_LDS, PT_PIN_INTERP != 0>(sd.tri_pos, 3 * tri, q0, q1, q2);
   const TriAttr at = load_attr<IN_LDS>(sd.tri_attr, tri);
   pos = mat3_mul(xyz(q0), xyz(q1), xyz(q2), wuv);
   if (normal) *normal = normalize(mat3_mul(at.n0, at.n1, at.n2, wuv));
@@ -1078,9 +1138,7 @@ __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const Shade
         // get_interpolated_data of the emitter; its normal, uv and material are only needed
         // if the walk lets the sample through, so only the position is formed here
         ++tally.hits;
-        q0 = fetch16<IN_LDS>(sd.tri_pos, 3 * etri);
-        q1 = fetch16<IN_LDS>(sd.tri_pos, 3 * etri + 1);
-        q2 = fetch16<IN_LDS>(sd.tri_pos, 3 * etri + 2);
+        fetch16x3<IN_LDS, PT_PIN_EMIT != 0>(sd.tri_pos, 3 * etri, q0, q1, q2);
         sample_pos = mat3_mul(xyz(q0), xyz(q1), xyz(q2), ewuv);
         l = sample_pos - pos;
         dist2 = dot(l, l);
