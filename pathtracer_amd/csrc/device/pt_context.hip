@@ -149,6 +149,7 @@ struct pt_ctx {
   uint32_t refill_chunk = 256;      // PT_REFILL_CHUNK
   uint32_t refill_blocks = 0;       // PT_REFILL_BLOCKS (0 = what is resident at once)
   bool shadow_refill = true;        // PT_SHADOW_REFILL=0: lane refill in k_extend only
+  bool child_entries = true;        // PT_CHILD_ENTRIES=0: traversal-stack entries as (record, side) even where the scene allows (ref << 7 | cnt)
   uint32_t sort_rays = 0;           // EXPERIMENT PT_SORT_RAYS: 1 = origin-major key, 2 = octant-major (wavefront pipeline only)
   uint32_t sort_bits = 6;           // PT_SORT_BITS: origin cell bits per axis
   uint32_t sort_shadow = 0;         // PT_SORT_SHADOW: also re-order the shadow queue
@@ -451,6 +452,7 @@ extern "C" pt_ctx* pt_create(int device) {
   if (const char* e = std::getenv("PT_EXTEND_REFILL")) ctx->refill_thresh = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   if (const char* e = std::getenv("PT_REFILL_CHUNK")) ctx->refill_chunk = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   if (const char* e = std::getenv("PT_SHADOW_REFILL")) ctx->shadow_refill = std::atoi(e) != 0;
+  if (const char* e = std::getenv("PT_CHILD_ENTRIES")) ctx->child_entries = std::atoi(e) != 0;
   if (const char* e = std::getenv("PT_REFILL_BLOCKS")) ctx->refill_blocks = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   if (ctx->refill_thresh > 64) ctx->refill_thresh = 64;
   if (ctx->refill_chunk < 64) ctx->refill_chunk = 64;
@@ -616,6 +618,10 @@ static int upload_one(pt_ctx* ctx, const pt_scene_desc* s) {
       }
     }
     d.pair_count = static_cast<uint32_t>(order.size());
+    // (ref << 7 | cnt) stack entries: every record and triangle index below 2^25, every leaf below 128 triangles
+    d.packed_stack = (order.size() < (1u << 25) && ntri < (1u << 25)) ? 1u : 0u;
+    for (size_t n = 0; n < s->bvh_node_count && d.packed_stack; ++n)
+      if (N[n].triangle_count >= 128u) d.packed_stack = 0;
     d.root_ref = N[0].triangle_count ? N[0].left_or_begin : 0u;
     d.root_cnt = N[0].triangle_count;
     if ((rc = dev_upload(ctx, ctx->scene_bufs, &d.pairs, reinterpret_cast<const float4*>(rec.data()), 4 * order.size())) != PT_OK)
@@ -779,6 +785,7 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
   // resident in the 256 MiB Infinity Cache instead of streaming through HBM every
   // iteration; a band is still several waves per SIMD of work (DESIGN.md "Banding").
   pt_dev_scene sc = ctx->scene;
+  if (!ctx->child_entries) sc.packed_stack = 0;
   const uint32_t n_lights = sc.directional_light_count + sc.point_light_count + (pc.emissive_triangle_count ? 1u : 0u);
   uint32_t band_slots = ctx->band_slots ? ctx->band_slots : total_slots;
   band_slots = (band_slots + 63u) & ~63u;
@@ -837,6 +844,7 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
 
   auto timed_on = [&](hipStream_t on, int kind, auto&& launch) {
     ++launches[kind];
+    if (ctx->log_launches) std::fprintf(stderr, "[pt] launch of kernel kind %d (1 extend, 2 shade, 3 shadow, 4 paths)\n", kind);
     if (time_kernels) {
       hipEvent_t a = next_kernel_event(ctx, ev_used);
       hipEvent_t b = next_kernel_event(ctx, ev_used);

@@ -46,6 +46,7 @@ struct pt_dev_scene {
   uint32_t scene_in_lds;             // 1: the scene (pair records, triangle positions; for shading also attributes, materials, lights, emitter list) is staged whole in the workgroup's LDS
   uint32_t all_opaque;               // 1: no surface can report alpha != 1 (shadow rays may stop at the first hit)
   uint32_t any_texture;              // 0: no material names a texture (kernels without sampling code)
+  uint32_t packed_stack;             // scenes in global memory: a traversal-stack entry can hold a child as (ref << 7 | cnt)
   uint32_t lds_stack_levels;         // scenes in global memory: traversal-stack rows kept in LDS per lane; deeper entries overflow to
                                      // private memory (0: all stack_entries rows in LDS). Set per render by the host.
 };

@@ -212,6 +212,11 @@ struct Tracer {
   uint32_t stack;         // LDS byte address of this lane's column of the traversal stack
   uint32_t stride;        // bytes from one level to the next
   uint32_t stack_end;     // scenes in global memory: LDS byte address one past this lane's last LDS row; pushes beyond it go to private memory
+#ifdef PT_GUARD
+  uint32_t g_pairs, g_tris;
+#endif
+  bool child_entries;     // scenes in global memory: a stack entry is the deferred child itself, (ref << 7 | cnt), so a pop is no
+                          // fetch (pt_dev_scene::packed_stack: every ref < 2^25, every leaf < 128 triangles); else (record << 1 | side)
 };
 
 // Rows of the traversal stack beyond a lane's LDS rows (scenes in global memory may run with a short LDS stack so that
@@ -255,6 +260,15 @@ __device__ __forceinline__ float4 fetch16(const float4* base, uint32_t index) {
 #endif
 #ifndef PT_PIN_ATTR
 #define PT_PIN_ATTR 1
+#endif
+#ifdef PT_GUARD
+#define PT_CHECK(cond, what, a, b)                                                                       \
+  if (!(cond)) {                                                                                         \
+    printf("[guard] %s: %u %u (block %u thread %u)\n", what, (unsigned)(a), (unsigned)(b), blockIdx.x, threadIdx.x); \
+    return false;                                                                                        \
+  }
+#else
+#define PT_CHECK(cond, what, a, b)
 #endif
 typedef float pt_f4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 as_float4(pt_f4 v) { return make_float4(v.x, v.y, v.z, v.w); }
@@ -429,6 +443,16 @@ __device__ __forceinline__ void traverse(const Tracer& tr, vec3 o, vec3 d, Hit& 
     uint32_t deep[kDeepLevels];  // rows beyond the lane's LDS rows (private memory; nd counts them)
     uint32_t nd = 0;
     for (;;) {
+#ifdef PT_GUARD
+      if (cnt > 0 ? (ref + cnt > tr.g_tris) : (ref >= tr.g_pairs)) {
+        printf("[guard] traverse: ref %u cnt %u nd %u (block %u thread %u)\n", ref, cnt, nd, blockIdx.x, threadIdx.x);
+        return;
+      }
+      if (nd > kDeepLevels || sp < tr.stack || sp > tr.stack_end) {
+        printf("[guard] traverse stack: sp %u nd %u (block %u thread %u)\n", sp, nd, blockIdx.x, threadIdx.x);
+        return;
+      }
+#endif
       if (cnt > 0) {
         if (ANY_HIT) {
           for (uint32_t i = 0; i < cnt; ++i) {
@@ -450,7 +474,10 @@ __device__ __forceinline__ void traverse(const Tracer& tr, vec3 o, vec3 d, Hit& 
         if (hit_l || hit_r) {
           const bool go_left = hit_l && (!hit_r || dist_l < dist_r);
           if (hit_l && hit_r) {
-            const uint32_t e = (ref << 1) | (go_left ? 1u : 0u);
+            // the far side. On these scenes the rate of divergent lane loads is the bound, so the 8-byte fetch a pop would
+            // need to turn (record, side) into the child is worth avoiding: rocks -7 %, atrium -2.4 % frame time
+            const uint32_t e = tr.child_entries ? ((go_left ? fbits(q3.z) : fbits(q3.x)) << 7) | (go_left ? fbits(q3.w) : fbits(q3.y))
+                                                : (ref << 1) | (go_left ? 1u : 0u);
             if (sp != tr.stack_end) {
               stack_store(sp, e);
               sp += tr.stride;
@@ -471,9 +498,14 @@ __device__ __forceinline__ void traverse(const Tracer& tr, vec3 o, vec3 d, Hit& 
         sp -= tr.stride;
         e = stack_load(sp);
       }
-      const uint2 c = fetch_child<IN_LDS>(tr.pairs, e >> 1, e & 1u);
-      ref = c.x;
-      cnt = c.y;
+      if (tr.child_entries) {  // wave-uniform
+        ref = e >> 7;
+        cnt = e & 127u;
+      } else {
+        const uint2 c = fetch_child<IN_LDS>(tr.pairs, e >> 1, e & 1u);
+        ref = c.x;
+        cnt = c.y;
+      }
     }
   }
 }
@@ -499,6 +531,11 @@ __device__ __forceinline__ Tracer make_tracer(const pt_dev_scene& sc, uint32_t* 
   tr.stack = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds + threadIdx.x));  // flat LDS address -> LDS offset (its low 32 bits)
   tr.stride = 4u * blockDim.x;
   tr.stack_end = 0xFFFFFFFFu;
+#ifdef PT_GUARD
+  tr.g_pairs = sc.pair_count;
+  tr.g_tris = sc.triangle_count;
+#endif
+  tr.child_entries = !IN_LDS && sc.packed_stack != 0;
   if (!IN_LDS) tr.stack_end = tr.stack + (sc.lds_stack_levels ? sc.lds_stack_levels : sc.stack_entries) * tr.stride;
   return tr;
 }
@@ -886,6 +923,12 @@ __device__ __forceinline__ void trav_begin(const Tracer& tr, vec3 o, vec3 d, Tra
 
 template <bool ANY_HIT>
 __device__ __forceinline__ bool trav_step(const Tracer& tr, TravState& s, uint32_t* deep, Tally& tally) {  // false: the traversal has ended
+#ifdef PT_GUARD
+  if (s.cnt > 0) { PT_CHECK(s.ref + s.cnt <= tr.g_tris, "leaf range", s.ref, s.cnt) }
+  else { PT_CHECK(s.ref < tr.g_pairs, "pair ref", s.ref, tr.g_pairs) }
+  PT_CHECK(s.nd <= kDeepLevels, "deep count", s.nd, 0)
+  PT_CHECK(s.sp >= tr.stack && s.sp <= tr.stack_end, "lds sp", s.sp, tr.stack_end)
+#endif
   if (s.cnt > 0) {
     if (ANY_HIT) {
       for (uint32_t i = 0; i < s.cnt; ++i) {
@@ -907,11 +950,13 @@ __device__ __forceinline__ bool trav_step(const Tracer& tr, TravState& s, uint32
     if (hit_l || hit_r) {
       const bool go_left = hit_l && (!hit_r || dist_l < dist_r);
       if (hit_l && hit_r) {
-        const uint32_t e = (s.ref << 1) | (go_left ? 1u : 0u);
+        const uint32_t e = tr.child_entries ? ((go_left ? fbits(q3.z) : fbits(q3.x)) << 7) | (go_left ? fbits(q3.w) : fbits(q3.y))
+                                            : (s.ref << 1) | (go_left ? 1u : 0u);
         if (s.sp != tr.stack_end) {
           stack_store(s.sp, e);
           s.sp += tr.stride;
         } else {
+          PT_CHECK(s.nd < kDeepLevels, "deep push", s.nd, 0)
           deep[s.nd++] = e;
         }
       }
@@ -928,9 +973,14 @@ __device__ __forceinline__ bool trav_step(const Tracer& tr, TravState& s, uint32
     s.sp -= tr.stride;
     e = stack_load(s.sp);
   }
-  const uint2 c = fetch_child<false>(tr.pairs, e >> 1, e & 1u);
-  s.ref = c.x;
-  s.cnt = c.y;
+  if (tr.child_entries) {
+    s.ref = e >> 7;
+    s.cnt = e & 127u;
+  } else {
+    const uint2 c = fetch_child<false>(tr.pairs, e >> 1, e & 1u);
+    s.ref = c.x;
+    s.cnt = c.y;
+  }
   return true;
 }
 

@@ -134,7 +134,7 @@ def test_rank_split_matches_oracle_per_rank(renderer, oracle):
                                  {"PT_PIPELINE": "wavefront", "PT_SORT_RAYS": "1", "PT_SORT_SHADOW": "1"},
                                  {"PT_CONCURRENT_BANDS": "3", "PT_BAND_MIN_TILES": "1"},
                                  {"PT_CONCURRENT_BANDS": "7", "PT_BAND_MIN_TILES": "1", "PT_PATHS_VERTICES": "5"},
-                                 {"PT_CONCURRENT_BANDS": "1"}])
+                                 {"PT_CONCURRENT_BANDS": "1"}, {"PT_CHILD_ENTRIES": "0"}])
 def test_alternative_pipelines_give_the_same_bits(oracle, monkeypatch, env):
     """The wavefront pipeline (k_extend + k_shade, fused or with the split k_shadow, lazy or per-iteration
     compaction, with or without the k_paths tail) and other k_paths launch shapes: same results as the default."""
