@@ -23,6 +23,7 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "
           "-Wall", "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(CSRC, "device")]
 DEVICE_SRC = [os.path.join(CSRC, "device", f) for f in ("pt_kernels.hip", "pt_context.hip", "pt_sort.hip")]
 FAST_SRC = os.path.join(CSRC, "device", "pt_kernels_fast.hip")
+RS_SRC = os.path.join(CSRC, "device", "pt_kernels_rs.hip")  # the traversal kernels with (record, side) stack entries
 HOST_SRC = [os.path.join(CSRC, "host", f) for f in ("bvh_builder.cpp", "scene_pack.cpp")]
 
 
@@ -54,7 +55,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         # source with FMA contraction allowed: the fast-arithmetic build of the path kernel.
         os.makedirs(OBJ_DIR, exist_ok=True)
         fast_flags = [f if f != "-ffp-contract=off" else "-ffp-contract=fast" for f in COMMON]
-        jobs = [(src, COMMON) for src in srcs] + [(FAST_SRC, fast_flags)]
+        jobs = [(src, COMMON) for src in srcs] + [(FAST_SRC, fast_flags), (RS_SRC, COMMON)]
         objs = []
         cmds = []
         for src, flags in jobs:

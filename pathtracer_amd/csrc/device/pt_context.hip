@@ -145,10 +145,6 @@ struct pt_ctx {
   uint32_t lds_stack = 16;          // PT_LDS_STACK: traversal-stack rows in LDS per lane for scenes in global memory (0 = the whole depth).
                                     // 16 rows + private-memory overflow: the 4.7 M-triangle rocks (depth 33) go from 4 to 7 k_extend waves
                                     // per SIMD (-21 % k_extend time) and k_paths +5 %; shallower trees are unaffected (measured)
-  uint32_t refill_thresh = 0;       // EXPERIMENT PT_EXTEND_REFILL: parked lanes that trigger a refill (0 = plain k_extend)
-  uint32_t refill_chunk = 256;      // PT_REFILL_CHUNK
-  uint32_t refill_blocks = 0;       // PT_REFILL_BLOCKS (0 = what is resident at once)
-  bool shadow_refill = true;        // PT_SHADOW_REFILL=0: lane refill in k_extend only
   bool child_entries = true;        // PT_CHILD_ENTRIES=0: traversal-stack entries as (record, side) even where the scene allows (ref << 7 | cnt)
   uint32_t sort_rays = 0;           // EXPERIMENT PT_SORT_RAYS: 1 = origin-major key, 2 = octant-major (wavefront pipeline only)
   uint32_t sort_bits = 6;           // PT_SORT_BITS: origin cell bits per axis
@@ -449,13 +445,7 @@ extern "C" pt_ctx* pt_create(int device) {
   if (const char* e = std::getenv("PT_SPLIT_SHADOW")) ctx->split_shadow = std::strtoul(e, nullptr, 10) != 0;
   if (const char* e = std::getenv("PT_TAIL_ENTRIES")) ctx->tail_entries = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   if (const char* e = std::getenv("PT_LDS_STACK")) ctx->lds_stack = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
-  if (const char* e = std::getenv("PT_EXTEND_REFILL")) ctx->refill_thresh = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
-  if (const char* e = std::getenv("PT_REFILL_CHUNK")) ctx->refill_chunk = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
-  if (const char* e = std::getenv("PT_SHADOW_REFILL")) ctx->shadow_refill = std::atoi(e) != 0;
   if (const char* e = std::getenv("PT_CHILD_ENTRIES")) ctx->child_entries = std::atoi(e) != 0;
-  if (const char* e = std::getenv("PT_REFILL_BLOCKS")) ctx->refill_blocks = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
-  if (ctx->refill_thresh > 64) ctx->refill_thresh = 64;
-  if (ctx->refill_chunk < 64) ctx->refill_chunk = 64;
   if (const char* e = std::getenv("PT_SORT_RAYS")) ctx->sort_rays = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   if (const char* e = std::getenv("PT_SORT_BITS")) ctx->sort_bits = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   if (const char* e = std::getenv("PT_SORT_SHADOW")) ctx->sort_shadow = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
@@ -800,6 +790,14 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
     sc.lds_stack_levels = ctx->lds_stack;  // short LDS stack, the rest of the depth in private memory (kDeepLevels = 48 rows)
     trace_block = 256u;
   }
+  // The traversal kernels exist in two compilations (pt_kernels.hip, PT_STACK_CHILD): stack entries that hold the deferred child
+  // itself for scenes that allow it, (record, side) entries otherwise. LDS-resident scenes use neither format (their own).
+  const bool rs = !sc.scene_in_lds && !sc.packed_stack;
+  const auto launch_extend = rs ? ptd_rs::launch_extend : ptd::launch_extend;
+  const auto launch_shade = rs ? ptd_rs::launch_shade : ptd::launch_shade;
+  const auto launch_shadow = rs ? ptd_rs::launch_shadow : ptd::launch_shadow;
+  const auto launch_paths_exact = rs ? ptd_rs::launch_paths : ptd::launch_paths;
+  const auto launch_paths = (ctx->fast_arith && !rs) ? ptd_fast::launch_paths : launch_paths_exact;  // the fast build has packed entries only
   const int pipeline = no_alloc ? 0 : ctx->pipeline;
   // Concurrent bands (path pipeline): the frame is cut into `conc` bands of tiles, each with its own state, queues and stream,
   // and their launches are enqueued alternately. Every k_paths launch ends with a tail in which most of the GPU idles while the
@@ -815,9 +813,6 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
     while (conc > 1 && tiles / conc < ctx->band_min_tiles) --conc;  // a band should still fill the GPU (4096 waves resident) on its own
     if (conc > 1) band_slots = ((tiles + conc - 1) / conc) * 64u;
   }
-  // (Choosing the wavefront pipeline with lane refill per scene was measured and dropped: +7 % on the 4.7 M-triangle rocks at
-  // 16 spp, -2 % at the config's 484 spp, where k_shade's state traffic outweighs what the refill saves)
-  const uint32_t refill_thresh = ctx->refill_thresh, refill_chunk = ctx->refill_chunk;
   const bool split = pipeline == 1 && ctx->split_shadow && !sc.scene_in_lds && n_lights != 0;
   int rc = PT_OK;
   if (no_alloc) {
@@ -907,7 +902,7 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
         if (r.drained || r.vertices >= max_iters) continue;
         any = true;
         timed_on(r.s, PT_K_PATHS, [&] {
-          (ctx->fast_arith ? ptd_fast::launch_paths : ptd::launch_paths)(
+          launch_paths(
               sc, r.f, *r.st, r.k & 1u, PT_CNT_QUEUE0 + r.k % 3u, PT_CNT_QUEUE0 + (r.k + 1u) % 3u, PT_CNT_QUEUE0 + (r.k + 2u) % 3u, r.bound,
               trace_block < ctx->paths_block_threads ? trace_block : ctx->paths_block_threads, ctx->paths_blocks, ctx->paths_vertices,
               sc.scene_in_lds ? 0u : ctx->xcd_chunk, r.s);
@@ -975,7 +970,7 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
       uint64_t vertices = 0;
       for (uint32_t k = 0; !drained && vertices < max_iters; ++k, vertices += ctx->paths_vertices) {
         timed(PT_K_PATHS, [&] {
-          (ctx->fast_arith ? ptd_fast::launch_paths : ptd::launch_paths)(
+          launch_paths(
                             sc, f, st, k & 1u, PT_CNT_QUEUE0 + k % 3u, PT_CNT_QUEUE0 + (k + 1u) % 3u, PT_CNT_QUEUE0 + (k + 2u) % 3u, bound,
                             trace_block < ctx->paths_block_threads ? trace_block : ctx->paths_block_threads, ctx->paths_blocks,
                             ctx->paths_vertices, sc.scene_in_lds ? 0u : ctx->xcd_chunk, stream);
@@ -1002,16 +997,12 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
               return fail(ctx, PT_ERR_DEVICE, "radix sort failed");
             pt_dev_state sorted = st;
             sorted.queue[parity] = ctx->sort_queue_out;
-            timed(PT_K_EXTEND, [&] { ptd::launch_extend(sc, sorted, parity, bound, trace_block, ctx->trace_blocks, stream); });
-          } else if (refill_thresh && !sc.scene_in_lds && trace_block == 256) {
-            timed(PT_K_EXTEND, [&] {
-              ptd::launch_extend_refill(sc, st, parity, bound, ctx->refill_blocks, refill_chunk, refill_thresh, stream);
-            });
+            timed(PT_K_EXTEND, [&] { launch_extend(sc, sorted, parity, bound, trace_block, ctx->trace_blocks, stream); });
           } else {
-            timed(PT_K_EXTEND, [&] { ptd::launch_extend(sc, st, parity, bound, trace_block, ctx->trace_blocks, stream); });
+            timed(PT_K_EXTEND, [&] { launch_extend(sc, st, parity, bound, trace_block, ctx->trace_blocks, stream); });
           }
           timed(PT_K_SHADE, [&] {
-            ptd::launch_shade(sc, f, st, parity, bound, trace_block, ctx->shade_blocks, n_lights != 0, split, compact, stream);
+            launch_shade(sc, f, st, parity, bound, trace_block, ctx->shade_blocks, n_lights != 0, split, compact, stream);
           });
           if (split && ctx->sort_rays && ctx->sort_shadow) {
             // shadow queue by the shadow origin (pend[2]) and the first light sample's direction (req[0])
@@ -1023,12 +1014,8 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
               return fail(ctx, PT_ERR_DEVICE, "radix sort failed");
             pt_dev_state sorted = st;
             sorted.queue_shadow = ctx->sort_shadow_out;
-            timed(PT_K_SHADOW, [&] { ptd::launch_shadow(sc, f, sorted, bound, trace_block, ctx->trace_blocks, stream); });
-          } else if (split && refill_thresh && sc.all_opaque && !sc.scene_in_lds && trace_block == 256 && ctx->shadow_refill) {
-            timed(PT_K_SHADOW, [&] {
-              ptd::launch_shadow_refill(sc, f, st, bound, ctx->refill_blocks, refill_chunk, refill_thresh, stream);
-            });
-          } else if (split) timed(PT_K_SHADOW, [&] { ptd::launch_shadow(sc, f, st, bound, trace_block, ctx->trace_blocks, stream); });
+            timed(PT_K_SHADOW, [&] { launch_shadow(sc, f, sorted, bound, trace_block, ctx->trace_blocks, stream); });
+          } else if (split) timed(PT_K_SHADOW, [&] { launch_shadow(sc, f, st, bound, trace_block, ctx->trace_blocks, stream); });
           if (compact) parity ^= 1u;
         }
         PT_HIP(ctx, hipGetLastError());
@@ -1037,7 +1024,7 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
         if (!drained && bound <= ctx->tail_entries) {
           // short queue: every remaining vertex of every queued slot in one k_paths launch
           timed(PT_K_PATHS, [&] {
-            ptd::launch_paths(sc, f, st, parity, PT_CNT_QUEUE0 + parity, PT_CNT_QUEUE2, PT_CNT_QUEUE0 + (parity ^ 1u), bound, trace_block,
+            launch_paths_exact(sc, f, st, parity, PT_CNT_QUEUE0 + parity, PT_CNT_QUEUE2, PT_CNT_QUEUE0 + (parity ^ 1u), bound, trace_block,
                               0xFFFFFFFFu, max_vertices_u32, 0u, stream);
           });
           PT_HIP(ctx, hipGetLastError());

@@ -46,7 +46,7 @@ struct pt_dev_scene {
   uint32_t scene_in_lds;             // 1: the scene (pair records, triangle positions; for shading also attributes, materials, lights, emitter list) is staged whole in the workgroup's LDS
   uint32_t all_opaque;               // 1: no surface can report alpha != 1 (shadow rays may stop at the first hit)
   uint32_t any_texture;              // 0: no material names a texture (kernels without sampling code)
-  uint32_t packed_stack;             // scenes in global memory: a traversal-stack entry can hold a child as (ref << 7 | cnt)
+  uint32_t packed_stack;             // scenes in global memory: a traversal-stack entry can hold a child as (ref << 7 | cnt): the ptd kernels; else ptd_rs
   uint32_t lds_stack_levels;         // scenes in global memory: traversal-stack rows kept in LDS per lane; deeper entries overflow to
                                      // private memory (0: all stack_entries rows in LDS). Set per render by the host.
 };
@@ -96,10 +96,6 @@ void launch_shadow(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_s
 void launch_paths(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity, uint32_t cnt_in,
                   uint32_t cnt_out, uint32_t cnt_zero, uint32_t max_entries, uint32_t block, uint32_t max_blocks,
                   uint32_t max_vertices, uint32_t xcd_chunk, hipStream_t s);
-void launch_shadow_refill(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t max_entries, uint32_t blocks,
-                          uint32_t chunk, uint32_t thresh, hipStream_t s);
-void launch_extend_refill(const pt_dev_scene& sc, const pt_dev_state& st, uint32_t parity, uint32_t max_entries, uint32_t blocks,
-                          uint32_t chunk, uint32_t thresh, hipStream_t s);
 // experiment: ray re-ordering (pt_sort.hip)
 size_t sort_temp_bytes(uint32_t n);
 void launch_ray_keys(const pt_dev_state& st, const uint32_t* queue, uint32_t counter_word, uint32_t bound, const float* lo, const float* hi,
@@ -110,6 +106,19 @@ void launch_sum_stats(const pt_dev_state& st, hipStream_t s);
 void launch_finalize(const pt_dev_frame& f, const pt_dev_state& st, float4* accum_out, uint32_t* primary_out, hipStream_t s);
 void launch_resolve(const float4* accum, uint32_t pixel_count, uint32_t* rgba8, hipStream_t s);
 }  // namespace ptd
+
+namespace ptd_rs {  // pt_kernels_rs.hip: the traversal kernels with (record, side) stack entries (scenes that fail pt_dev_scene::packed_stack)
+void launch_extend(const pt_dev_scene& sc, const pt_dev_state& st, uint32_t parity, uint32_t max_entries, uint32_t block,
+                   uint32_t max_blocks, hipStream_t s);
+void launch_shade(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity,
+                  uint32_t max_entries, uint32_t block, uint32_t max_blocks, bool has_lights, bool split, bool compact,
+                  hipStream_t s);
+void launch_shadow(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t max_entries, uint32_t block,
+                   uint32_t max_blocks, hipStream_t s);
+void launch_paths(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity, uint32_t cnt_in,
+                  uint32_t cnt_out, uint32_t cnt_zero, uint32_t max_entries, uint32_t block, uint32_t max_blocks,
+                  uint32_t max_vertices, uint32_t xcd_chunk, hipStream_t s);
+}  // namespace ptd_rs
 
 namespace ptd_fast {  // pt_kernels_fast.hip: k_paths with the shading half on hardware-approximate arithmetic (PT_ARITH=fast)
 void launch_paths(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity, uint32_t cnt_in,

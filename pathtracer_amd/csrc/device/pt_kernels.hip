@@ -25,12 +25,28 @@
 
 using namespace ptd;
 
-// This file is compiled twice: as it stands (the exact build: namespace ptd, every kernel) and, through
+// This file is compiled three times: as it stands (the exact build: namespace ptd, every kernel); through
 // pt_kernels_fast.hip, with PT_FAST_ARITH defined and -ffp-contract=fast (the fast-arithmetic build of the path
-// kernel only: namespace ptd_fast, k_paths and launch_paths; see pt_vec.h for what "fast" changes).
+// kernel only: namespace ptd_fast, k_paths and launch_paths; see pt_vec.h for what "fast" changes); and through
+// pt_kernels_rs.hip with PT_STACK_CHILD 0 (namespace ptd_rs: the traversal kernels with (record, side) stack entries, for
+// scenes whose children do not fit a packed entry).
+//
+// PT_STACK_CHILD (scenes in global memory): 1 = a traversal-stack entry is the deferred child itself, (ref << 7 | cnt), so a
+// pop is no fetch — on these scenes the rate of divergent lane loads is the bound (rocks -7 %, atrium -2.4 % frame time);
+// needs every ref < 2^25 and every leaf < 128 triangles (pt_dev_scene::packed_stack, checked at upload). 0 = the entry is
+// (record << 1 | side) and a pop fetches the child's 8 bytes. The choice is made at COMPILE time on purpose: as a wave-uniform
+// bool tested inside the traversal loops, hipcc (ROCm 7.2) materialised the condition with v_cmp under the exec mask of one
+// loop and re-used that lane mask in another loop under a different exec mask, so a push and its pop could disagree on the
+// entry format (GPU memory fault, found the hard way).
+#ifndef PT_STACK_CHILD
+#define PT_STACK_CHILD 1
+#endif
 #ifdef PT_FAST_ARITH
 #define PT_KNS ptk_fast
 #define PT_LNS ptd_fast
+#elif !PT_STACK_CHILD
+#define PT_KNS ptk_exact_rs
+#define PT_LNS ptd_rs
 #else
 #define PT_KNS ptk_exact
 #define PT_LNS ptd
@@ -215,8 +231,6 @@ struct Tracer {
 #ifdef PT_GUARD
   uint32_t g_pairs, g_tris;
 #endif
-  bool child_entries;     // scenes in global memory: a stack entry is the deferred child itself, (ref << 7 | cnt), so a pop is no
-                          // fetch (pt_dev_scene::packed_stack: every ref < 2^25, every leaf < 128 triangles); else (record << 1 | side)
 };
 
 // Rows of the traversal stack beyond a lane's LDS rows (scenes in global memory may run with a short LDS stack so that
@@ -474,10 +488,11 @@ __device__ __forceinline__ void traverse(const Tracer& tr, vec3 o, vec3 d, Hit& 
         if (hit_l || hit_r) {
           const bool go_left = hit_l && (!hit_r || dist_l < dist_r);
           if (hit_l && hit_r) {
-            // the far side. On these scenes the rate of divergent lane loads is the bound, so the 8-byte fetch a pop would
-            // need to turn (record, side) into the child is worth avoiding: rocks -7 %, atrium -2.4 % frame time
-            const uint32_t e = tr.child_entries ? ((go_left ? fbits(q3.z) : fbits(q3.x)) << 7) | (go_left ? fbits(q3.w) : fbits(q3.y))
-                                                : (ref << 1) | (go_left ? 1u : 0u);
+#if PT_STACK_CHILD  // the far side: the child itself, or (record, side)
+            const uint32_t e = ((go_left ? fbits(q3.z) : fbits(q3.x)) << 7) | (go_left ? fbits(q3.w) : fbits(q3.y));
+#else
+            const uint32_t e = (ref << 1) | (go_left ? 1u : 0u);
+#endif
             if (sp != tr.stack_end) {
               stack_store(sp, e);
               sp += tr.stride;
@@ -498,14 +513,14 @@ __device__ __forceinline__ void traverse(const Tracer& tr, vec3 o, vec3 d, Hit& 
         sp -= tr.stride;
         e = stack_load(sp);
       }
-      if (tr.child_entries) {  // wave-uniform
-        ref = e >> 7;
-        cnt = e & 127u;
-      } else {
-        const uint2 c = fetch_child<IN_LDS>(tr.pairs, e >> 1, e & 1u);
-        ref = c.x;
-        cnt = c.y;
-      }
+#if PT_STACK_CHILD
+      ref = e >> 7;
+      cnt = e & 127u;
+#else
+      const uint2 c = fetch_child<IN_LDS>(tr.pairs, e >> 1, e & 1u);
+      ref = c.x;
+      cnt = c.y;
+#endif
     }
   }
 }
@@ -535,7 +550,6 @@ __device__ __forceinline__ Tracer make_tracer(const pt_dev_scene& sc, uint32_t* 
   tr.g_pairs = sc.pair_count;
   tr.g_tris = sc.triangle_count;
 #endif
-  tr.child_entries = !IN_LDS && sc.packed_stack != 0;
   if (!IN_LDS) tr.stack_end = tr.stack + (sc.lds_stack_levels ? sc.lds_stack_levels : sc.stack_entries) * tr.stride;
   return tr;
 }
@@ -843,6 +857,7 @@ __device__ __forceinline__ void camera_ray(const pt_dev_frame& f, uint32_t x, ui
 // =========================================================================== kernels
 
 #ifndef PT_FAST_ARITH
+namespace PT_KNS {  // kernels live in the build's own namespace: the same template compiled twice must not share a symbol
 // First sample of every slot; fills queue 0 with the live slots (compacted: padding slots
 // of partial tiles never enter a queue).
 __global__ __launch_bounds__(256) void k_init(pt_dev_frame f, pt_dev_state st) {
@@ -898,153 +913,7 @@ __global__ __launch_bounds__(256) void k_extend(pt_dev_scene sc, pt_dev_state st
   flush_tally(tally, st, PT_K_EXTEND);
 }
 
-#endif  // !PT_FAST_ARITH
-
-// ---- one traversal in resumable form: the state a lane carries from trip to trip, and ONE trip of the
-// global-memory loop of traverse() (an inner visit, a leaf's triangle tests, or a pop — same order, same culls).
-struct TravState {
-  vec3 o, d, inv;
-  Hit h;
-  uint32_t ref, cnt, sp;
-  uint32_t nd;  // rows in the caller's private overflow array
-};
-
-__device__ __forceinline__ void trav_begin(const Tracer& tr, vec3 o, vec3 d, TravState& s, Tally& tally) {
-  ++tally.rays;
-  s.o = o;
-  s.d = d;
-  s.inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
-  s.h = Hit{kInfinity, 0.0f, 0.0f, kNoHit};
-  s.sp = tr.stack;
-  s.nd = 0;
-  s.ref = tr.root_ref;
-  s.cnt = tr.root_cnt;
-}
-
-template <bool ANY_HIT>
-__device__ __forceinline__ bool trav_step(const Tracer& tr, TravState& s, uint32_t* deep, Tally& tally) {  // false: the traversal has ended
-#ifdef PT_GUARD
-  if (s.cnt > 0) { PT_CHECK(s.ref + s.cnt <= tr.g_tris, "leaf range", s.ref, s.cnt) }
-  else { PT_CHECK(s.ref < tr.g_pairs, "pair ref", s.ref, tr.g_pairs) }
-  PT_CHECK(s.nd <= kDeepLevels, "deep count", s.nd, 0)
-  PT_CHECK(s.sp >= tr.stack && s.sp <= tr.stack_end, "lds sp", s.sp, tr.stack_end)
-#endif
-  if (s.cnt > 0) {
-    if (ANY_HIT) {
-      for (uint32_t i = 0; i < s.cnt; ++i) {
-        ++tally.tests;
-        ray_triangle<false>(tr, s.o, s.d, s.ref + i, s.h);
-        if (s.h.tri != kNoHit) return false;
-      }
-    } else {
-      tally.tests += s.cnt;
-      for (uint32_t i = 0; i < s.cnt; ++i) ray_triangle<false>(tr, s.o, s.d, s.ref + i, s.h);
-    }
-  } else {
-    ++tally.visits;
-    const float4 q0 = fetch16<false>(tr.pairs, 4 * s.ref), q1 = fetch16<false>(tr.pairs, 4 * s.ref + 1);
-    const float4 q2 = fetch16<false>(tr.pairs, 4 * s.ref + 2), q3 = fetch16<false>(tr.pairs, 4 * s.ref + 3);
-    float dist_l, dist_r;
-    bool hit_l, hit_r;
-    ray_box_pair(s.o, s.inv, q0, q1, q2, s.h.t, hit_l, hit_r, dist_l, dist_r);
-    if (hit_l || hit_r) {
-      const bool go_left = hit_l && (!hit_r || dist_l < dist_r);
-      if (hit_l && hit_r) {
-        const uint32_t e = tr.child_entries ? ((go_left ? fbits(q3.z) : fbits(q3.x)) << 7) | (go_left ? fbits(q3.w) : fbits(q3.y))
-                                            : (s.ref << 1) | (go_left ? 1u : 0u);
-        if (s.sp != tr.stack_end) {
-          stack_store(s.sp, e);
-          s.sp += tr.stride;
-        } else {
-          PT_CHECK(s.nd < kDeepLevels, "deep push", s.nd, 0)
-          deep[s.nd++] = e;
-        }
-      }
-      s.ref = go_left ? fbits(q3.x) : fbits(q3.z);
-      s.cnt = go_left ? fbits(q3.y) : fbits(q3.w);
-      return true;
-    }
-  }
-  uint32_t e;
-  if (s.nd != 0) {
-    e = deep[--s.nd];
-  } else {
-    if (s.sp == tr.stack) return false;
-    s.sp -= tr.stride;
-    e = stack_load(s.sp);
-  }
-  if (tr.child_entries) {
-    s.ref = e >> 7;
-    s.cnt = e & 127u;
-  } else {
-    const uint2 c = fetch_child<false>(tr.pairs, e >> 1, e & 1u);
-    s.ref = c.x;
-    s.cnt = c.y;
-  }
-  return true;
-}
-
-#ifndef PT_FAST_ARITH
-// EXPERIMENT (PT_EXTEND_REFILL): k_extend for scenes in global memory as persistent waves with LANE REFILL. A wave owns
-// a stream of queue entries (chunks of `chunk` consecutive entries, dealt round-robin over the waves); a lane whose
-// traversal has ended parks until `thresh` lanes are parked, then all of them store their hit and take the next
-// entries of the stream. The wave's trips are then filled with ~64 - thresh/2 rays instead of the 15 of 64 that a
-// wave of fixed membership averages on these scenes (its slowest ray sets its trip count). Per ray nothing changes.
-#ifndef PT_EXTEND_REFILL_MIN_WAVES
-#define PT_EXTEND_REFILL_MIN_WAVES 1
-#endif
-__global__ __launch_bounds__(256, PT_EXTEND_REFILL_MIN_WAVES) void k_extend_refill(pt_dev_scene sc, pt_dev_state st, uint32_t parity, uint32_t chunk, uint32_t thresh) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
-  const uint32_t n = st.counters[PT_CNT_QUEUE0 + parity];
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    st.counters[PT_CNT_QUEUE0 + (parity ^ 1u)] = 0;
-    st.counters[PT_CNT_SHADOW] = 0;
-  }
-  Tally tally;
-  const Tracer tr = make_tracer<false>(sc, lds_dyn);
-  const uint32_t waves_total = gridDim.x * (blockDim.x >> 6);
-  const uint32_t wave_gid = blockIdx.x * (blockDim.x >> 6) + wave_id();
-  auto queue_index = [&](uint32_t v) { return ((v / chunk) * waves_total + wave_gid) * chunk + v % chunk; };
-  uint32_t vnext = 0;  // wave-uniform
-  bool live = false, pending = false;
-  uint32_t slot = 0;
-  TravState s{};
-  uint32_t deep[kDeepLevels];  // stack rows beyond the lane's LDS rows (private memory)
-  bool exhausted = queue_index(0) >= n;
-  for (;;) {
-    const uint64_t idle = __ballot(!live);
-    const uint32_t n_idle = static_cast<uint32_t>(__popcll(idle));
-    if (!exhausted && n_idle >= thresh) {
-      if (!live) {
-        if (pending) {
-          st.hit[slot] = make_uint4(s.h.tri, fbits(s.h.u), fbits(s.h.v), fbits(s.h.t));
-          pending = false;
-        }
-        const uint32_t q = queue_index(vnext + mbcnt(idle));
-        if (q < n) {
-          slot = st.queue[parity][q];
-          const float4 d4 = st.ray_d[slot];
-          if (d4.w == 0.0f) {  // else: retired since the queue was last compacted
-            const float4 o4 = st.ray_o[slot];
-            trav_begin(tr, xyz(o4), xyz(d4), s, tally);
-            live = true;
-            pending = true;
-          }
-        }
-      }
-      vnext += n_idle;
-      exhausted = queue_index(vnext) >= n;  // the stream is monotonic in v: nothing left for this wave
-    }
-    if (__ballot(live) == 0) {
-      if (exhausted) break;
-      continue;
-    }
-    if (live) live = trav_step<false>(tr, s, deep, tally);
-  }
-  if (pending) st.hit[slot] = make_uint4(s.h.tri, fbits(s.h.u), fbits(s.h.v), fbits(s.h.t));
-  flush_tally(tally, st, PT_K_EXTEND);
-}
-
+}  // namespace PT_KNS
 #endif  // !PT_FAST_ARITH
 
 // ray_scene_intersect_with_transparency, main.comp:306-332. Returns the transparency and
@@ -1390,6 +1259,7 @@ __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const Shade
 #define PT_PATHS_MIN_WAVES_GLOBAL 5  // scenes beyond an XCD's L2: swept 3..6 on cfg3/cfg4-class scenes, best at 5
 #endif
 #ifndef PT_FAST_ARITH
+namespace PT_KNS {  // kernels live in the build's own namespace: the same template compiled twice must not share a symbol
 // shade_vertex for every extended ray, then compaction of the survivors into the next queue.
 // Persistent workgroups striding the queue, so the LDS scene copy is staged once per block.
 template <bool IN_LDS, bool ALL_OPAQUE, bool SPLIT>
@@ -1532,119 +1402,7 @@ __global__ __launch_bounds__(256, ALL_OPAQUE ? PT_SHADOW_MIN_WAVES_OPAQUE : PT_S
   flush_tally(walks, st, PT_K_SHADOW);
 }
 
-// k_shadow for all-opaque scenes in global memory as persistent waves with LANE REFILL (see k_extend_refill): the any-hit
-// walks end after very different trip counts, so a wave of fixed membership idles most lanes. Here a lane whose walk has
-// ended parks; once `thresh` lanes are parked they book their sample (same expressions, same order as k_shadow), go on to
-// the slot's next light or finish the slot and take the next entry of the wave's stream. Per slot nothing changes.
-#ifndef PT_SHADOW_REFILL_MIN_WAVES
-#define PT_SHADOW_REFILL_MIN_WAVES 1
-#endif
-__global__ __launch_bounds__(256, PT_SHADOW_REFILL_MIN_WAVES) void k_shadow_refill(pt_dev_scene sc, pt_dev_frame f, pt_dev_state st, uint32_t chunk, uint32_t thresh) {
-  extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
-  const uint32_t n = st.counters[PT_CNT_SHADOW];
-  Tally walks;
-  const uint32_t n_lights = sc.directional_light_count + sc.point_light_count + (f.pc.emissive_triangle_count ? 1u : 0u);
-  const vec3 bg_linear = mk(f.bg_linear[0], f.bg_linear[1], f.bg_linear[2]);
-  const size_t ss = st.slot_stride;
-  const Tracer tr = make_tracer<false>(sc, lds_dyn);
-  const uint32_t waves_total = gridDim.x * (blockDim.x >> 6);
-  const uint32_t wave_gid = blockIdx.x * (blockDim.x >> 6) + wave_id();
-  auto queue_index = [&](uint32_t v) { return ((v / chunk) * waves_total + wave_gid) * chunk + v % chunk; };
-  uint32_t vnext = 0;  // wave-uniform
-  bool live = false, has_slot = false, pending = false;
-  uint32_t slot = 0, j = 0;
-  vec3 punctual = splat(0.0f), area_light = splat(0.0f);
-  TravState s{};
-  uint32_t deep[kDeepLevels];
-  bool exhausted = queue_index(0) >= n;
-  for (;;) {
-    const bool want = !live && (has_slot || !exhausted);
-    const uint32_t n_want = static_cast<uint32_t>(__popcll(__ballot(want)));
-    const bool any_live = __ballot(live) != 0;
-    if (n_want >= thresh || (!any_live && n_want != 0)) {
-      if (want && pending) {  // a walk has ended: main.comp:445-455 / :485-498 for an all-opaque scene
-        pending = false;
-        if (s.h.tri == kNoHit) {  // transparency 1; the distance test needs a hit, so it cannot hold
-          const float4* r = st.req + (static_cast<size_t>(j) * 4u) * ss + slot;
-          const float4 r1 = r[ss], r2 = r[2 * ss], r3 = r[3 * ss];
-          const float transparency = 1.0f;
-          walks.taps += fbits(r3.z);
-          const vec3 c = xyz(r1) * transparency * xyz(r2) * r2.w / r3.x;
-          if (f.pc.emissive_triangle_count && j + 1 == n_lights) area_light = c;
-          else punctual = punctual + c;
-        }
-        ++j;
-      }
-      for (int pass = 0; pass < 2; ++pass) {
-        if (want && has_slot && !live) {
-          while (j < n_lights) {  // the slot's next light sample
-            const float4* r = st.req + (static_cast<size_t>(j) * 4u) * ss + slot;
-            const float4 r0 = r[0];
-            const vec3 l = xyz(r0);
-            if (f.pc.emissive_triangle_count && j + 1 == n_lights) {  // the emitter-first shortcut
-              const float4 r3 = r[3 * ss];
-              Hit sh{kInfinity, 0.0f, 0.0f, kNoHit};
-              ++walks.tests;
-              ray_triangle<false>(tr, s.o, l, fbits(r3.y), sh);
-              if (sh.tri != kNoHit) {
-                ++walks.rays;
-                ++walks.paths;  // shortcut count (see shade_vertex)
-                ++j;
-                continue;
-              }
-            }
-            trav_begin(tr, s.o, l, s, walks);
-            live = true;
-            pending = true;
-            break;
-          }
-          if (!live) {  // every light is booked: the vertex's colour, as in k_shadow
-            const float4* h = st.pend + slot;
-            const float4 h0 = h[0], h1 = h[ss], h3 = h[3 * ss];
-            vec3 direct = xyz(h0);
-            direct = direct + punctual;
-            direct = direct + area_light;
-            const vec3 color = xyz(h3) + direct * h0.w * xyz(h1);
-            if (fbits(h1.w) & 1u) {
-              float4 acc = st.accum[slot];
-              finish_sample(color, xyz(h[4 * ss]), bg_linear, acc, walks);
-              st.accum[slot] = acc;
-            } else {
-              float4 pb = st.path_b[slot];
-              pb.x = color.x;
-              pb.y = color.y;
-              pb.z = color.z;
-              st.path_b[slot] = pb;
-            }
-            has_slot = false;
-          }
-        }
-        if (pass == 0 && !exhausted) {  // wave-uniform: lanes without a slot take the next entries of the stream
-          const bool need = want && !has_slot;
-          const uint64_t m = __ballot(need);
-          if (need) {
-            const uint32_t q = queue_index(vnext + mbcnt(m));
-            if (q < n) {
-              slot = st.queue_shadow[q];
-              s.o = xyz(st.pend[2 * ss + slot]);
-              j = 0;
-              punctual = splat(0.0f);
-              area_light = splat(0.0f);
-              has_slot = true;
-            }
-          }
-          vnext += static_cast<uint32_t>(__popcll(m));
-          exhausted = queue_index(vnext) >= n;
-        }
-      }
-    } else if (!any_live) {
-      break;
-    }
-    if (live) live = trav_step<true>(tr, s, deep, walks);
-  }
-  flush_tally(walks, st, PT_K_SHADOW);
-}
-
+}  // namespace PT_KNS
 #endif  // !PT_FAST_ARITH
 
 // The path kernel: every queued slot advances by up to `max_vertices` path vertices — extend,
@@ -1731,6 +1489,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_paths(pt_dev_scene sc, pt_de
 using namespace PT_KNS;
 
 #ifndef PT_FAST_ARITH
+namespace PT_KNS {  // kernels live in the build's own namespace: the same template compiled twice must not share a symbol
 // Column sums of the per-block counter table: one workgroup per kernel slice, so the host reads
 // PT_K_COUNT x PT_ST_WORDS words instead of the whole table (16 MB at 1080p: ~1.5 ms of the frame's wall time).
 __global__ __launch_bounds__(256) void k_sum_stats(pt_dev_state st) {
@@ -1779,6 +1538,7 @@ __global__ __launch_bounds__(256) void k_resolve(const float4* __restrict__ accu
   rgba8[i] = r | (g << 8) | (b << 16) | (255u << 24);
 }
 
+}  // namespace PT_KNS
 #endif  // !PT_FAST_ARITH
 
 // =========================================================================== launchers
@@ -1813,44 +1573,12 @@ void launch_extend(const pt_dev_scene& sc, const pt_dev_state& st, uint32_t pari
   else hipLaunchKernelGGL(k_extend<false>, dim3(grid), dim3(block), trace_lds_bytes(sc, block), s, sc, st, parity);
 }
 
-void launch_extend_refill(const pt_dev_scene& sc, const pt_dev_state& st, uint32_t parity, uint32_t max_entries, uint32_t blocks,
-                          uint32_t chunk, uint32_t thresh, hipStream_t s) {
-  const uint32_t block = 256;
-  const size_t lds = trace_lds_bytes(sc, block);
-  if (!blocks) {  // what is resident at once: a persistent grid
-    int per_cu = 0, cus = 0, dev = 0;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_extend_refill, block, lds);
-    blocks = static_cast<uint32_t>(per_cu > 0 ? per_cu : 1) * static_cast<uint32_t>(cus > 0 ? cus : 256);
-  }
-  uint32_t grid = blocks_for(max_entries, block);
-  if (grid > blocks) grid = blocks;
-  hipLaunchKernelGGL(k_extend_refill, dim3(grid), dim3(block), lds, s, sc, st, parity, chunk, thresh);
-}
-
 void launch_shadow(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t max_entries, uint32_t block,
                    uint32_t max_blocks, hipStream_t s) {
   uint32_t grid = blocks_for(max_entries, block);
   if (grid > max_blocks) grid = max_blocks;
   if (sc.all_opaque) hipLaunchKernelGGL(k_shadow<true>, dim3(grid), dim3(block), trace_lds_bytes(sc, block), s, sc, f, st);
   else hipLaunchKernelGGL(k_shadow<false>, dim3(grid), dim3(block), trace_lds_bytes(sc, block), s, sc, f, st);
-}
-
-void launch_shadow_refill(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t max_entries, uint32_t blocks,
-                          uint32_t chunk, uint32_t thresh, hipStream_t s) {
-  const uint32_t block = 256;
-  const size_t lds = trace_lds_bytes(sc, block);
-  if (!blocks) {
-    int per_cu = 0, cus = 0, dev = 0;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_shadow_refill, block, lds);
-    blocks = static_cast<uint32_t>(per_cu > 0 ? per_cu : 1) * static_cast<uint32_t>(cus > 0 ? cus : 256);
-  }
-  uint32_t grid = blocks_for(max_entries, block);
-  if (grid > blocks) grid = blocks;
-  hipLaunchKernelGGL(k_shadow_refill, dim3(grid), dim3(block), lds, s, sc, f, st, chunk, thresh);
 }
 
 void launch_shade(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity,

@@ -16,12 +16,12 @@ from pathtracer_amd.renderer import Renderer  # noqa: E402
 COUNTERS = ["paths", "rays", "node_visits", "tri_tests", "hits_shaded", "texture_taps", "shaded_vertices", "nan_samples"]
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-ENVS = [{}, {"PT_CONCURRENT_BANDS": "3", "PT_BAND_MIN_TILES": "1"}, {"PT_PIPELINE": "wavefront", "PT_EXTEND_REFILL": "16", "PT_REFILL_CHUNK": "64"},
+ENVS = [{}, {"PT_CONCURRENT_BANDS": "3", "PT_BAND_MIN_TILES": "1"}, {"PT_PIPELINE": "wavefront", "PT_LDS_STACK": "4"},
         {"PT_PIPELINE": "wavefront", "PT_TAIL_ENTRIES": "0"}, {"PT_LDS_SCENE_BYTES": "0", "PT_CONCURRENT_BANDS": "2", "PT_BAND_MIN_TILES": "2"}]
 oracle = oracle_lib.load()
 bad = 0
 for e_i, env in enumerate(ENVS):
-    for k in ("PT_CONCURRENT_BANDS", "PT_BAND_MIN_TILES", "PT_PIPELINE", "PT_EXTEND_REFILL", "PT_REFILL_CHUNK", "PT_TAIL_ENTRIES", "PT_LDS_SCENE_BYTES"):
+    for k in ("PT_CONCURRENT_BANDS", "PT_BAND_MIN_TILES", "PT_PIPELINE", "PT_LDS_STACK", "PT_TAIL_ENTRIES", "PT_LDS_SCENE_BYTES"):
         os.environ.pop(k, None)
     os.environ.update(env)
     r = Renderer(0)

@@ -128,9 +128,6 @@ def test_rank_split_matches_oracle_per_rank(renderer, oracle):
                                  {"PT_BAND_SLOTS": "4096"}, {"PT_BAND_SLOTS": "4096", "PT_PIPELINE": "wavefront"},
                                  {"PT_XCD_CHUNK": "5"}, {"PT_XCD_CHUNK": "100000", "PT_PATHS_BLOCKS": "24"},
                                  {"PT_LDS_STACK": "2"}, {"PT_LDS_STACK": "3", "PT_PIPELINE": "wavefront"}, {"PT_LDS_STACK": "0"},
-                                 {"PT_PIPELINE": "wavefront", "PT_EXTEND_REFILL": "16", "PT_REFILL_CHUNK": "64", "PT_LDS_STACK": "4"},
-                                 {"PT_PIPELINE": "wavefront", "PT_EXTEND_REFILL": "16", "PT_SHADOW_REFILL": "0"},
-                                 {"PT_PIPELINE": "wavefront", "PT_EXTEND_REFILL": "40", "PT_REFILL_CHUNK": "128", "PT_TAIL_ENTRIES": "0"},
                                  {"PT_PIPELINE": "wavefront", "PT_SORT_RAYS": "1", "PT_SORT_SHADOW": "1"},
                                  {"PT_CONCURRENT_BANDS": "3", "PT_BAND_MIN_TILES": "1"},
                                  {"PT_CONCURRENT_BANDS": "7", "PT_BAND_MIN_TILES": "1", "PT_PATHS_VERTICES": "5"},
