@@ -131,7 +131,8 @@ def test_rank_split_matches_oracle_per_rank(renderer, oracle):
                                  {"PT_PIPELINE": "wavefront", "PT_SORT_RAYS": "1", "PT_SORT_SHADOW": "1"},
                                  {"PT_CONCURRENT_BANDS": "3", "PT_BAND_MIN_TILES": "1"},
                                  {"PT_CONCURRENT_BANDS": "7", "PT_BAND_MIN_TILES": "1", "PT_PATHS_VERTICES": "5"},
-                                 {"PT_CONCURRENT_BANDS": "1"}, {"PT_CHILD_ENTRIES": "0"}])
+                                 {"PT_CONCURRENT_BANDS": "1"}, {"PT_CHILD_ENTRIES": "0"},
+                                 {"PT_CHILD_ENTRIES": "0", "PT_PIPELINE": "wavefront", "PT_LDS_STACK": "3"}])
 def test_alternative_pipelines_give_the_same_bits(oracle, monkeypatch, env):
     """The wavefront pipeline (k_extend + k_shade, fused or with the split k_shadow, lazy or per-iteration
     compaction, with or without the k_paths tail) and other k_paths launch shapes: same results as the default."""
@@ -145,6 +146,21 @@ def test_alternative_pipelines_give_the_same_bits(oracle, monkeypatch, env):
         compare(r, oracle, scenes.soup_scene(20000, emissive_every=50), 96, 54, 9, seed=34)           # global memory, all opaque
     finally:
         r.close()
+
+
+def test_leaf_too_large_for_packed_stack_entries(renderer, oracle):
+    """A leaf of 128 triangles or more (here 150 copies of one triangle: the builder cannot split them) does not fit the
+    packed (ref << 7 | cnt) stack entry, so the upload selects the kernels with (record, side) entries (pt_kernels_rs.hip)."""
+    s = scenes.soup_scene(3000, seed=5, emissive_every=40)
+    v, t = s.vertices, s.triangles
+    one = v[t[7]]
+    s.vertices = np.concatenate([v] + [one] * 150)
+    extra = len(v) + np.arange(3 * 150, dtype=np.uint32).reshape(150, 3)
+    s.triangles = np.concatenate([t, extra])
+    packed = renderer.pack(s)
+    assert int(packed.packed_nodes["triangle_count"].max()) >= 128
+    st = compare(renderer, oracle, s, 96, 54, 9, seed=35, bg=(0.5, 0.7, 1.0))
+    assert st["scene_in_lds"] == 0
 
 
 def test_zero_samples_gives_black_not_a_hang(renderer, oracle):
