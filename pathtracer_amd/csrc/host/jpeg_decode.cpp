@@ -1,9 +1,11 @@
-// Baseline JPEG decode (ITU T.81 sequential DCT, 8-bit, Huffman) to RGBA8 — what the reference gets from stb_image
-// through tinygltf for .jpg textures (gltf_loader.cc:279-291; Sponza-class assets ship them). Written from the
-// standard: SOF0/SOF1 frames, 1 (grey) or 3 (YCbCr) components, sampling factors 1..4 in any combination, restart
+// JPEG decode (ITU T.81 DCT-based, 8-bit, Huffman: sequential SOF0/SOF1 and progressive SOF2) to RGBA8 — what the
+// reference gets from stb_image through tinygltf for .jpg textures (gltf_loader.cc:279-291; Sponza-class assets ship
+// them). Written from the standard: 1 (grey) or 3 (YCbCr) components, sampling factors 1..4 in any combination, restart
 // intervals, 8- and 16-bit quantisation tables, JFIF colour conversion, triangle-filter ("fancy") upsampling for the
-// common 2x1 / 2x2 chroma layouts and replication otherwise. Progressive (SOF2), arithmetic-coded, lossless and 12-bit
-// streams are refused with a message that names the frame type.
+// common 2x1 / 2x2 chroma layouts and replication otherwise; progressive frames by spectral selection and successive
+// approximation (annex G: DC first / refinement scans, AC first / refinement scans with end-of-band runs), coefficients
+// kept per component until the last scan. Arithmetic-coded, lossless, hierarchical and 12-bit streams are refused with a
+// message that names the frame type.
 // The decoded pixels of a lossy codec are decoder-defined: IDCT rounding and chroma upsampling differ between stb_image,
 // libjpeg and this file by a few code values ("parity unpinned" for JPEG texels; PNG texels are exact).
 #include <cmath>
@@ -35,6 +37,7 @@ struct Component {
   int dc_pred = 0;
   int blocks_w = 0, blocks_h = 0;  // padded to whole MCUs
   std::vector<unsigned char> plane;  // blocks_w*8 x blocks_h*8 samples
+  std::vector<int16_t> coefs;        // progressive frames: 64 coefficients per block (natural order), filled scan by scan
 };
 
 struct BitReader {
@@ -174,7 +177,7 @@ void decode_jpeg_rgba8(const unsigned char* bytes, size_t size, uint32_t& width,
   std::vector<Component> comps;
   int restart_interval = 0;
   int hmax = 1, vmax = 1;
-  bool have_frame = false, adobe = false;
+  bool have_frame = false, adobe = false, progressive = false;
   int adobe_transform = -1;
   size_t pos = 2;
 
@@ -231,11 +234,13 @@ void decode_jpeg_rgba8(const unsigned char* bytes, size_t size, uint32_t& width,
       adobe = true;
       adobe_transform = d[11];
     } else if (marker >= 0xC0 && marker <= 0xCF && marker != 0xC4 && marker != 0xC8 && marker != 0xCC) {  // SOFn
-      if (marker != 0xC0 && marker != 0xC1) {
-        const char* what = marker == 0xC2 ? "progressive" : (marker == 0xC3 ? "lossless" : (marker >= 0xC9 ? "arithmetic-coded" : "hierarchical"));
+      if (marker != 0xC0 && marker != 0xC1 && marker != 0xC2) {
+        const char* what = marker == 0xC3 ? "lossless" : (marker >= 0xC9 ? "arithmetic-coded" : "hierarchical");
         throw std::runtime_error(std::string("JPEG: ") + what + " JPEG (SOF" + std::to_string(marker - 0xC0) +
-                                 ") is not supported; re-encode as baseline JPEG or PNG");
+                                 ") is not supported; re-encode as baseline or progressive Huffman JPEG, or PNG");
       }
+      if (have_frame) throw std::runtime_error("JPEG: second frame header");
+      progressive = marker == 0xC2;
       if (n < 6) throw std::runtime_error("JPEG: bad SOF");
       if (d[0] != 8) throw std::runtime_error("JPEG: only 8-bit samples are supported");
       height = be16(d + 1);
@@ -243,6 +248,8 @@ void decode_jpeg_rgba8(const unsigned char* bytes, size_t size, uint32_t& width,
       const int nc = d[5];
       if (!width || !height || (nc != 1 && nc != 3) || n < static_cast<size_t>(6 + 3 * nc))
         throw std::runtime_error("JPEG: unsupported frame (size 0 or component count not 1 / 3)");
+      if (static_cast<uint64_t>(width) * height > (1ull << 28))  // 16384 x 16384: a damaged header must not become a 12 GB allocation
+        throw std::runtime_error("JPEG: frame larger than 2^28 pixels");
       comps.assign(static_cast<size_t>(nc), Component());
       for (int k = 0; k < nc; ++k) {
         comps[k].id = d[6 + 3 * k];
@@ -254,11 +261,16 @@ void decode_jpeg_rgba8(const unsigned char* bytes, size_t size, uint32_t& width,
         if (comps[k].v > vmax) vmax = comps[k].v;
       }
       have_frame = true;
-    } else if (marker == 0xDA) {  // SOS: baseline has one scan with all components (or one per component)
+    } else if (marker == 0xDA) {  // SOS: sequential frames have one scan with all components (or one per component)
       if (!have_frame) throw std::runtime_error("JPEG: SOS before SOF");
       if (n < 1) throw std::runtime_error("JPEG: bad SOS");
       const int ns = d[0];
       if (ns < 1 || ns > static_cast<int>(comps.size()) || n < static_cast<size_t>(1 + 2 * ns + 3)) throw std::runtime_error("JPEG: bad SOS");
+      // spectral selection [ss, se] and successive approximation (ah: bit position of the previous scan of this band, al: of this one)
+      const int ss = d[1 + 2 * ns], se = d[2 + 2 * ns], ah = d[3 + 2 * ns] >> 4, al = d[3 + 2 * ns] & 15;
+      if (progressive && (ss > se || se > 63 || (ss == 0 && se != 0) || (ss > 0 && ns != 1) || al > 13 || (ah != 0 && ah != al + 1)))
+        throw std::runtime_error("JPEG: bad progressive scan parameters");
+      const bool need_dc = !progressive || (ss == 0 && ah == 0), need_ac = !progressive || ss > 0;
       std::vector<int> scan;
       for (int k = 0; k < ns; ++k) {
         int idx = -1;
@@ -267,7 +279,8 @@ void decode_jpeg_rgba8(const unsigned char* bytes, size_t size, uint32_t& width,
         if (idx < 0) throw std::runtime_error("JPEG: scan names an unknown component");
         comps[idx].td = d[2 + 2 * k] >> 4;
         comps[idx].ta = d[2 + 2 * k] & 15;
-        if (comps[idx].td > 3 || comps[idx].ta > 3 || !dc[comps[idx].td].defined || !ac[comps[idx].ta].defined || !qt_defined[comps[idx].tq])
+        if (comps[idx].td > 3 || comps[idx].ta > 3 || (need_dc && !dc[comps[idx].td].defined) || (need_ac && !ac[comps[idx].ta].defined) ||
+            (!progressive && !qt_defined[comps[idx].tq]))
           throw std::runtime_error("JPEG: scan uses an undefined table");
         scan.push_back(idx);
       }
@@ -278,9 +291,100 @@ void decode_jpeg_rgba8(const unsigned char* bytes, size_t size, uint32_t& width,
           c.blocks_w = static_cast<int>(mcus_x) * c.h;
           c.blocks_h = static_cast<int>(mcus_y) * c.v;
           c.plane.assign(static_cast<size_t>(c.blocks_w) * 8 * c.blocks_h * 8, 128);
+          if (progressive) c.coefs.assign(static_cast<size_t>(c.blocks_w) * c.blocks_h * 64, 0);
         }
       BitReader br{bytes + pos + len, bytes + size};
+      int eobrun = 0;  // progressive AC scans: blocks still to come whose band holds nothing new (T.81 G.1.2.2)
+      // refinement of a coefficient that is already non-zero: one correction bit, applied away from zero (G.1.2.3)
+      auto refine = [&](int16_t& c) {
+        if (br.bit() && (c & (1 << al)) == 0) c = static_cast<int16_t>(c >= 0 ? c + (1 << al) : c - (1 << al));
+      };
+      auto decode_block_progressive = [&](Component& c, int bx, int by) {
+        int16_t* coef = &c.coefs[(static_cast<size_t>(by) * c.blocks_w + bx) * 64];
+        if (ss == 0) {  // DC scan
+          if (ah == 0) {
+            const int t = decode_symbol(br, dc[c.td]);
+            if (t > 11) throw std::runtime_error("JPEG: bad DC category");
+            c.dc_pred += extend(br.bits(t), t);
+            coef[0] = static_cast<int16_t>(c.dc_pred * (1 << al));
+          } else if (br.bit()) {
+            coef[0] = static_cast<int16_t>(coef[0] | (1 << al));
+          }
+          return;
+        }
+        if (ah == 0) {  // AC band, first scan
+          if (eobrun > 0) {
+            --eobrun;
+            return;
+          }
+          for (int k = ss; k <= se;) {
+            const int rs = decode_symbol(br, ac[c.ta]);
+            const int r = rs >> 4, s = rs & 15;
+            if (s == 0) {
+              if (r < 15) {  // EOBn: this block and 2^r - 1 + extra more end here
+                eobrun = (1 << r) - 1;
+                if (r) eobrun += br.bits(r);
+                break;
+              }
+              k += 16;  // ZRL
+              continue;
+            }
+            k += r;
+            if (k > se) throw std::runtime_error("JPEG: AC run past the band");
+            coef[kZigZag[k]] = static_cast<int16_t>(extend(br.bits(s), s) * (1 << al));
+            ++k;
+          }
+          return;
+        }
+        // AC band, refinement scan: new coefficients are +-1 << al, placed after `r` still-zero positions; every
+        // already non-zero coefficient passed on the way takes one correction bit
+        int k = ss;
+        if (eobrun == 0) {
+          while (k <= se) {
+            const int rs = decode_symbol(br, ac[c.ta]);
+            int r = rs >> 4;
+            const int s = rs & 15;
+            int value = 0;
+            if (s == 0) {
+              if (r < 15) {
+                eobrun = 1 << r;
+                if (r) eobrun += br.bits(r);
+                break;  // the rest of this block is refined below, as the first block of the run
+              }
+            } else {
+              if (s != 1) throw std::runtime_error("JPEG: bad refinement symbol");
+              value = br.bit() ? (1 << al) : -(1 << al);
+            }
+            while (k <= se) {
+              int16_t& z = coef[kZigZag[k]];
+              if (z != 0) {
+                refine(z);
+              } else {
+                if (r == 0) break;
+                --r;
+              }
+              ++k;
+            }
+            if (s) {
+              if (k > se) throw std::runtime_error("JPEG: AC run past the band");
+              coef[kZigZag[k]] = static_cast<int16_t>(value);
+            }
+            ++k;
+          }
+        }
+        if (eobrun > 0) {
+          for (; k <= se; ++k) {
+            int16_t& z = coef[kZigZag[k]];
+            if (z != 0) refine(z);
+          }
+          --eobrun;
+        }
+      };
       auto decode_block = [&](Component& c, int bx, int by) {
+        if (progressive) {
+          decode_block_progressive(c, bx, by);
+          return;
+        }
         int coef[64] = {0};
         const int t = decode_symbol(br, dc[c.td]);
         if (t > 11) throw std::runtime_error("JPEG: bad DC category");
@@ -316,7 +420,9 @@ void decode_jpeg_rgba8(const unsigned char* bytes, size_t size, uint32_t& width,
         br.p = q + 2;
         next_rst = (next_rst + 1) & 7;
         for (Component& c : comps) c.dc_pred = 0;
+        eobrun = 0;
       };
+      for (int idx : scan) comps[idx].dc_pred = 0;  // every scan starts its predictions anew (T.81 E.2.4)
       if (ns == 1) {  // non-interleaved: the component's own blocks, row by row, only those that cover the image
         Component& c = comps[scan[0]];
         const int bw = static_cast<int>((static_cast<uint64_t>(width) * c.h + 8u * hmax - 1) / (8u * hmax));
@@ -348,6 +454,19 @@ void decode_jpeg_rgba8(const unsigned char* bytes, size_t size, uint32_t& width,
     pos += len;
   }
   if (!have_frame || comps.empty() || comps[0].plane.empty()) throw std::runtime_error("JPEG: no image data");
+  if (progressive)  // all scans are in: dequantise and transform every block once
+    for (Component& c : comps) {
+      if (c.plane.empty()) throw std::runtime_error("JPEG: a component has no scan");
+      if (!qt_defined[c.tq]) throw std::runtime_error("JPEG: frame uses an undefined quantisation table");
+      int block[64];
+      for (int by = 0; by < c.blocks_h; ++by)
+        for (int bx = 0; bx < c.blocks_w; ++bx) {
+          const int16_t* coef = &c.coefs[(static_cast<size_t>(by) * c.blocks_w + bx) * 64];
+          for (int i = 0; i < 64; ++i) block[i] = coef[i];
+          idct_block(block, qt[c.tq], &c.plane[(static_cast<size_t>(by) * 8) * (static_cast<size_t>(c.blocks_w) * 8) + static_cast<size_t>(bx) * 8], c.blocks_w * 8);
+        }
+      c.coefs = std::vector<int16_t>();
+    }
 
   rgba.assign(static_cast<size_t>(width) * height * 4, 255);
   std::vector<unsigned char> ry, rcb, rcr;

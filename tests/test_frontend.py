@@ -310,10 +310,39 @@ def test_baseline_jpeg_decode_against_libjpeg(ptlib):
         assert got.shape == (67, 93, 4) and (got[..., 3] == 255).all()
         d = np.abs(got[..., :3].astype(int) - ref)
         assert d.max() <= 3 and d.mean() < 0.5, (kw, d.max(), d.mean())
-    b = io.BytesIO()
-    Image.fromarray(img).save(b, "JPEG", progressive=True)
-    with pytest.raises(RuntimeError):  # progressive (SOF2) is refused, by name, not mis-decoded
-        frontend.decode_image(b.getvalue())
+
+def test_progressive_jpeg_decode_against_libjpeg(ptlib):
+    """Progressive JPEG (SOF2: spectral selection + successive approximation, what stb_image also reads). libjpeg's
+    default progression has DC first / refinement scans and AC first / refinement scans with end-of-band runs; smooth and
+    noisy content, three chroma layouts, greyscale, restart intervals, low quality (long zero runs and EOB runs). Same bar
+    as the baseline test (decoder-defined rounding), and the coefficients of a progressive stream are those of the baseline
+    stream libjpeg writes for the same pixels, so both must decode to the same bytes here."""
+    import io
+    from PIL import Image
+    y, x = np.mgrid[0:131, 0:150]
+    smooth = np.stack([128 + 100 * np.sin(x / 9.0) * np.cos(y / 7.0), 128 + 90 * np.cos(x / 5.0 + y / 11.0), (x * 2 + y) % 256], -1)
+    noisy = smooth + np.random.RandomState(5).normal(0, 25, smooth.shape)
+    for name, src in (("smooth", smooth), ("noisy", noisy)):
+        img = src.clip(0, 255).astype(np.uint8)
+        for kw in (dict(subsampling=0), dict(subsampling=1), dict(subsampling=2), dict(subsampling=2, restart_marker_blocks=5),
+                   dict(subsampling=0, quality=20), dict(subsampling=2, quality=98), None):
+            prog, base = io.BytesIO(), io.BytesIO()
+            pil = Image.fromarray(img[..., 0]) if kw is None else Image.fromarray(img)
+            args = {"quality": 90, **(kw or {})}
+            pil.save(prog, "JPEG", progressive=True, **args)
+            pil.save(base, "JPEG", **args)
+            data = prog.getvalue()
+            assert b"\xff\xc2" in data and b"\xff\xc2" not in base.getvalue()
+            ref = np.array(Image.open(io.BytesIO(data)).convert("RGB")).astype(int)
+            got = frontend.decode_image(data)
+            assert got.shape == (131, 150, 4) and (got[..., 3] == 255).all()
+            d = np.abs(got[..., :3].astype(int) - ref)
+            assert d.max() <= 3 and d.mean() < 0.5, (name, kw, d.max(), d.mean())
+            assert np.array_equal(got, frontend.decode_image(base.getvalue())), (name, kw)
+    arith = bytearray(data)
+    arith[data.index(b"\xff\xc2") + 1] = 0xCA  # SOF10, progressive arithmetic-coded: refused by name, not mis-decoded
+    with pytest.raises(RuntimeError):
+        frontend.decode_image(bytes(arith))
 
 
 def test_truncated_jpeg_and_garbage_rejected(ptlib):
