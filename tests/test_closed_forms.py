@@ -11,9 +11,13 @@ for three scenes whose light transport closes after one or two vertices.
     and trace()'s lobe weight `c * (diffuse_pdf + microfacet_pdf)` (main.comp:571), whose second term is the pdf of the
     OTHER, unused sample.
 
-These are statistical checks (jittered samples), with tolerances a few times the measured noise and far below what a
+  * (exact, not statistical) the primary hit of every pixel at one sample per pixel against a float32 brute force over ALL
+    triangles, with the camera ray re-derived here from main():588-605 and triple32: the BVH traversal (main.comp:263-304) and
+    the builder's boxes lose no hit, invent none, and report a closest one — t equal bit for bit.
+
+The first three are statistical checks (jittered samples), with tolerances a few times the measured noise and far below what a
 misread factor (a missing 1/count, cos, 1/pi, the 2.2) would cause. Like tests/test_oracle_functions.py they do not pin
-parity with the reference (nothing can here); they remove the single-author risk for a8, a9, a13, a14 and a15."""
+parity with the reference (nothing can here); they remove the single-author risk for a1, a7, a8, a9, a10, a13, a14 and a15."""
 import numpy as np
 import pytest
 
@@ -374,3 +378,113 @@ def test_plane_under_an_emissive_quad_has_its_expected_radiance_on_the_cpu(alpha
 def test_plane_under_an_emissive_quad_has_its_expected_radiance_through_the_hip_path(alpha):
     packed, rp, accum, ids, _ = render_on("hip", emitter_scene(alpha), 32, 24, 1024, 9)
     check_emitter(alpha, packed, rp, accum, ids, 9)
+
+
+# ------------------------------------------------------------------ a1 + a7 (+ a16): BVH traversal against brute force
+
+F32 = np.float32
+
+
+def triple32_v(x):
+    """main.comp:135-143 on a uint32 array (https://nullprogram.com/blog/2018/07/31/)"""
+    x = x.astype(np.uint64)
+    for shift, mul in ((17, 0xED5AD4BB), (11, 0xAC4C1B51), (15, 0x31848BAB)):
+        x ^= x >> np.uint64(shift)
+        x = (x * np.uint64(mul)) & np.uint64(0xFFFFFFFF)
+    x ^= x >> np.uint64(14)
+    return x.astype(np.uint32)
+
+
+def dot_v(a, b):  # dot(): x*x + y*y + z*z, left to right, one float32 rounding per operation
+    return (a[..., 0] * b[..., 0] + a[..., 1] * b[..., 1]) + a[..., 2] * b[..., 2]
+
+
+def cross_v(a, b):
+    return np.stack([a[..., 1] * b[..., 2] - b[..., 1] * a[..., 2], a[..., 2] * b[..., 0] - b[..., 2] * a[..., 0],
+                     a[..., 0] * b[..., 1] - b[..., 0] * a[..., 1]], axis=-1)
+
+
+def first_camera_rays(rp, seed):
+    """The one ray per pixel of main():588-605 at sample_count 1, float32 operation by operation: state = index ^ seed, two
+    draws, pixel_center = corner + (x + (0 + r1) / 1) * du + (y + (0 + r2) / 1) * dv, dir = normalize(pixel_center - camera)."""
+    pc = rp.pc
+    w, h = pc.resolution_x, pc.resolution_y
+    cam = np.array(pc.camera_position[:], dtype=F32)
+    du, dv = np.array(pc.pixel_delta_u[:], dtype=F32), np.array(pc.pixel_delta_v[:], dtype=F32)
+    corner = np.array(pc.corner_pixel_pos[:], dtype=F32)
+    ys, xs = np.mgrid[0:h, 0:w]
+    state = triple32_v((ys * w + xs).astype(np.uint32) ^ np.uint32(seed))
+    r1 = state.astype(F32) / F32(0xFFFFFFFF)
+    state = triple32_v(state)
+    r2 = state.astype(F32) / F32(0xFFFFFFFF)
+    ax = xs.astype(F32) + (F32(0.0) + r1) / F32(1.0)
+    ay = ys.astype(F32) + (F32(0.0) + r2) / F32(1.0)
+    centre = (corner + ax[..., None] * du) + ay[..., None] * dv
+    d = centre - cam
+    inv = F32(1.0) / np.sqrt(dot_v(d, d))
+    return cam, d * inv[..., None]
+
+
+def brute_force_hits(origin, dirs, tri_pos):
+    """ray_triangle_intersect (main.comp:189-217) of every ray against EVERY triangle, float32 operation by operation; returns
+    t (rays, tris) with +inf where the triangle is not accepted."""
+    eps = F32(1e-6)
+    p0, p1, p2 = tri_pos[:, 0, :3], tri_pos[:, 1, :3], tri_pos[:, 2, :3]
+    edge1, edge2 = p1 - p0, p2 - p0
+    s = origin - p0
+    sce1 = cross_v(s, edge1)
+    t_all = np.full((dirs.shape[0], tri_pos.shape[0]), np.inf, dtype=F32)
+    for i in range(0, dirs.shape[0], 512):
+        d = dirs[i:i + 512, None, :]
+        rce2 = cross_v(d, edge2[None])
+        det = dot_v(edge1[None], rce2)
+        with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+            inv_det = F32(1.0) / det
+            u = inv_det * dot_v(s[None], rce2)
+            v = inv_det * dot_v(d, sce1[None])
+            t = inv_det * dot_v(edge2, sce1)[None]
+            ok = ~(np.abs(det) < eps) & ~((u < 0) | (u > 1)) & ~((v < 0) | (u + v > 1)) & (t > eps)
+        t_all[i:i + 512] = np.where(ok, t, np.inf)
+    return t_all
+
+
+def check_against_brute_force(packed, rp, ids, seed):
+    origin, dirs = first_camera_rays(rp, seed)
+    h, w = ids.shape
+    t = brute_force_hits(origin, dirs.reshape(-1, 3), packed.vertex_positions.reshape(-1, 3, 4).astype(F32))
+    tmin = t.min(axis=1)
+    ids = ids.reshape(-1)
+    hit = ids != 0xFFFFFFFF
+    assert 0.1 < hit.mean() < 0.999  # both outcomes occur
+    assert (np.isinf(tmin) == ~hit).all()                        # the tree loses no hit and invents none
+    assert (t[hit, ids[hit]] == tmin[hit]).all()                  # and the hit it reports is a closest one
+    unique = (t == tmin[:, None]).sum(axis=1) == 1
+    assert (np.argmin(t, axis=1)[hit & unique] == ids[hit & unique]).all()
+    assert (hit & unique).mean() > 0.1
+
+
+def brute_force_scene(which):
+    return scenes.rocks_scene(n_tris=6000) if which == "rocks" else scenes.atrium_scene(detail=2, tex_size=16)
+
+
+@pytest.mark.parametrize("which", ["rocks", "atrium"])
+def test_primary_hits_equal_a_brute_force_over_all_triangles_on_the_cpu(which, oracle, ptlib):
+    packed = PackedScene(brute_force_scene(which), ptlib)
+    rp = packed.render_params(ptlib, 96, 64, 1, (0.0, 0.0, 0.0), seed=77)
+    _, _, ids, _ = oracle_lib.render(oracle, packed, rp, threads=8)
+    check_against_brute_force(packed, rp, ids, 77)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["rocks", "atrium"])
+def test_primary_hits_equal_a_brute_force_over_all_triangles_through_the_hip_path(which):
+    from pathtracer_amd.renderer import Renderer
+    r = Renderer(0)
+    try:
+        packed = r.pack(brute_force_scene(which))
+        r.upload(packed)
+        rp = packed.render_params(r.lib, 96, 64, 1, (0.0, 0.0, 0.0), seed=77)
+        _, _, ids, _ = r.render_params(rp)
+    finally:
+        r.close()
+    check_against_brute_force(packed, rp, ids, 77)
