@@ -488,3 +488,43 @@ def test_primary_hits_equal_a_brute_force_over_all_triangles_through_the_hip_pat
     finally:
         r.close()
     check_against_brute_force(packed, rp, ids, 77)
+
+
+# ------------------------------------------------------------------ a17: the camera block of the push constants
+
+def test_camera_block_against_the_formulas_of_the_push_constants_constructor(ptlib):
+    """render_job.cc:846-872 in float64: w = normalize(-lookat), u = normalize(cross(up, w)), v = cross(w, u), viewport 2 high and
+    2 * rx / ry wide at focal length 1 / tan(fov / 2); and what they mean: the ray through the middle of the frame runs along
+    lookat, the top and bottom edges are fov apart, pixels are square."""
+    rs = np.random.RandomState(4)
+    verts = np.zeros(3, dtype=abi.VERTEX)
+    verts["position"] = ((0, 0, 0), (1, 0, 0), (0, 1, 0))
+    for case in range(12):
+        look = rs.normal(size=3)
+        look /= np.linalg.norm(look)
+        if abs(look[1]) > 0.95:
+            continue
+        pos, fov = rs.uniform(-5, 5, size=3), rs.uniform(0.2, 1.8)
+        rx, ry = int(rs.randint(8, 400)), int(rs.randint(8, 300))
+        scene = Scene(vertices=verts, triangles=np.array([[0, 1, 2]], dtype=np.uint32), camera_position=tuple(pos),
+                      camera_lookat=tuple(look), camera_vfov=float(fov))
+        pc = PackedScene(scene, ptlib).render_params(ptlib, rx, ry, 4, (0.0, 0.0, 0.0), seed=1).pc
+        pos32, look32, fov32 = np.float32(pos).astype(np.float64), np.float32(look).astype(np.float64), float(np.float32(fov))
+        w = -look32 / np.linalg.norm(look32)
+        u = np.cross([0.0, 1.0, 0.0], w)
+        u /= np.linalg.norm(u)
+        v = np.cross(w, u)
+        vu, vv = (2.0 * rx / ry) * u, -2.0 * v
+        want = {"camera_position": pos32, "pixel_delta_u": vu / rx, "pixel_delta_v": vv / ry,
+                "corner_pixel_pos": pos32 - w / np.tan(fov32 / 2.0) - 0.5 * (vu + vv)}
+        for name, val in want.items():
+            got = np.array(getattr(pc, name)[:3], dtype=np.float64)
+            assert np.allclose(got, val, rtol=0, atol=4e-6 * max(1.0, np.abs(val).max())), (case, name, got, val)
+        du, dv, corner = (np.array(getattr(pc, k)[:3], dtype=np.float64) for k in ("pixel_delta_u", "pixel_delta_v", "corner_pixel_pos"))
+        centre = corner + 0.5 * rx * du + 0.5 * ry * dv - pos32
+        assert np.allclose(centre / np.linalg.norm(centre), look32 / np.linalg.norm(look32), atol=1e-5)
+        top, bottom = corner + 0.5 * rx * du - pos32, corner + 0.5 * rx * du + ry * dv - pos32
+        angle = np.arccos(np.dot(top, bottom) / np.linalg.norm(top) / np.linalg.norm(bottom))
+        assert abs(angle - fov32) < 1e-5
+        assert abs(np.linalg.norm(du) - np.linalg.norm(dv)) < 1e-6 * np.linalg.norm(du) and abs(np.dot(du, dv)) < 1e-9
+        assert (pc.resolution_x, pc.resolution_y) == (rx, ry)
