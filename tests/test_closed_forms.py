@@ -15,9 +15,12 @@ for three scenes whose light transport closes after one or two vertices.
     triangles, with the camera ray re-derived here from main():588-605 and triple32: the BVH traversal (main.comp:263-304) and
     the builder's boxes lose no hit, invent none, and report a closest one — t equal bit for bit.
 
+  * (exact) the camera block against the PushConstants constructor's formulas and their geometric meaning, the packed arrays
+    against process_scene written out in numpy, and the invariants any correct tree over the triangles satisfies.
+
 The first three are statistical checks (jittered samples), with tolerances a few times the measured noise and far below what a
 misread factor (a missing 1/count, cos, 1/pi, the 2.2) would cause. Like tests/test_oracle_functions.py they do not pin
-parity with the reference (nothing can here); they remove the single-author risk for a1, a7, a8, a9, a10, a13, a14 and a15."""
+parity with the reference (nothing can here); they remove the single-author risk for a1, a6-a10 and a13-a17."""
 import numpy as np
 import pytest
 
@@ -528,3 +531,70 @@ def test_camera_block_against_the_formulas_of_the_push_constants_constructor(ptl
         assert abs(angle - fov32) < 1e-5
         assert abs(np.linalg.norm(du) - np.linalg.norm(dv)) < 1e-6 * np.linalg.norm(du) and abs(np.dot(du, dv)) < 1e-9
         assert (pc.resolution_x, pc.resolution_y) == (rx, ry)
+
+
+# ------------------------------------------------------------------ a6 + a16 + a17: the packed arrays and the tree's invariants
+
+@pytest.mark.parametrize("which", ["textured", "atrium", "rocks"])
+def test_packed_arrays_against_process_scene_and_tree_invariants(which, ptlib):
+    """render_job.cc:76-121 written out in numpy (positions as vec4(p, 0), the 64-byte vertex record, the emissive list by the
+    FIRST vertex's material: factor != 0 or an emissive texture, left_or_begin) and what any correct tree over these triangles
+    satisfies whatever split heuristic built it: leaves partition the (permuted) triangle list, a node's box is exactly the
+    bounds of its triangles' vertices, children sit side by side at (left, left + 1), the reported depth is the deepest leaf's."""
+    scene = {"textured": lambda: scenes.textured_scene(), "atrium": lambda: scenes.atrium_scene(detail=2, tex_size=16),
+             "rocks": lambda: scenes.rocks_scene(n_tris=6000)}[which]()
+    packed = PackedScene(scene, ptlib)
+    tris, verts = packed.triangles, scene.vertices
+    assert sorted(map(tuple, tris.tolist())) == sorted(map(tuple, scene.triangles.tolist()))  # a permutation of the input
+    flat = verts[tris.reshape(-1)]
+    assert np.array_equal(packed.vertex_positions[:, :3], flat["position"]) and (packed.vertex_positions[:, 3] == 0).all()
+    pv = packed.packed_vertex_data
+    assert np.array_equal(pv["position"][:, :3], flat["position"]) and (pv["position"][:, 3] == 0).all()
+    assert np.array_equal(pv["normal_and_texcoord_u"][:, :3], flat["normal"]) and np.array_equal(pv["normal_and_texcoord_u"][:, 3], flat["texcoord"][:, 0])
+    assert np.array_equal(pv["tangent_and_texcoord_v"][:, :3], flat["tangent"]) and np.array_equal(pv["tangent_and_texcoord_v"][:, 3], flat["texcoord"][:, 1])
+    assert np.array_equal(pv["bitangent"], flat["bitangent"]) and np.array_equal(pv["material_index"], flat["material_index"])
+    mats = scene.materials[verts["material_index"][tris[:, 0]]]
+    emissive = np.nonzero((mats["emissive_factor"] != 0).any(axis=1) | (mats["emissive_texture_index"] != -1))[0]
+    assert np.array_equal(packed.emissive, emissive.astype(np.uint32))
+    nodes, pn = packed.nodes, packed.packed_nodes
+    assert np.array_equal(pn["aabb_min"], nodes["aabb_min"]) and np.array_equal(pn["aabb_max"], nodes["aabb_max"])
+    assert np.array_equal(pn["triangle_count"], nodes["triangle_count"])
+    assert np.array_equal(pn["left_or_begin"], np.where(nodes["triangle_count"] > 0, nodes["begin_index"], nodes["left_child_index"]))
+    # the tree, walked from the root over the PACKED nodes (what the traversal reads)
+    tri_pos = flat["position"].reshape(-1, 3, 3)
+    seen = np.zeros(len(tris), dtype=np.int32)
+    deepest, stack = 0, [(0, 1)]
+    visited = 0
+
+    def bounds_of(node):  # triangle range under a node, and the exact bounds of its vertices
+        if pn["triangle_count"][node] > 0:
+            b = int(pn["left_or_begin"][node])
+            return b, b + int(pn["triangle_count"][node])
+        lo0, hi0 = bounds_of(int(pn["left_or_begin"][node]))
+        lo1, hi1 = bounds_of(int(pn["left_or_begin"][node]) + 1)
+        assert hi0 == lo1  # the children split a contiguous range
+        return lo0, hi1
+
+    import sys
+    sys.setrecursionlimit(10000)
+    while stack:
+        node, depth = stack.pop()
+        visited += 1
+        lo, hi = bounds_of(node) if visited <= 64 else (None, None)  # full range check near the root, leaves below
+        if pn["triangle_count"][node] > 0:
+            b, c = int(pn["left_or_begin"][node]), int(pn["triangle_count"][node])
+            seen[b:b + c] += 1
+            pts = tri_pos[b:b + c].reshape(-1, 3)
+            assert np.array_equal(pn["aabb_min"][node], pts.min(axis=0)) and np.array_equal(pn["aabb_max"][node], pts.max(axis=0))
+            deepest = max(deepest, depth)
+        else:
+            left = int(pn["left_or_begin"][node])
+            assert left % 2 == 0 and left + 1 < len(pn)  # an even-aligned pair: one 64-byte line
+            if lo is not None:
+                pts = tri_pos[lo:hi].reshape(-1, 3)
+                assert np.array_equal(pn["aabb_min"][node], pts.min(axis=0)) and np.array_equal(pn["aabb_max"][node], pts.max(axis=0))
+            assert (np.minimum(pn["aabb_min"][left], pn["aabb_min"][left + 1]) == pn["aabb_min"][node]).all()
+            assert (np.maximum(pn["aabb_max"][left], pn["aabb_max"][left + 1]) == pn["aabb_max"][node]).all()
+            stack += [(left, depth + 1), (left + 1, depth + 1)]
+    assert (seen == 1).all()
+    assert deepest == packed.bvh_max_depth
