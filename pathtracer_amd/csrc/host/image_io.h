@@ -10,8 +10,8 @@
 
 namespace pt {
 
-// Decodes a PNG (any colour type, bit depth 1..16, non-interlaced or Adam7) or a baseline JPEG to RGBA8.
-// Throws std::runtime_error on malformed input or an unsupported container / JPEG flavour (progressive etc.).
+// Decodes a PNG (any colour type, bit depth 1..16, non-interlaced or Adam7) or a JPEG (baseline or progressive) to RGBA8.
+// Throws std::runtime_error on malformed input or an unsupported container / JPEG flavour (arithmetic-coded, lossless, 12-bit).
 void decode_image_rgba8(const unsigned char* bytes, size_t size, uint32_t& width, uint32_t& height,
                         std::vector<unsigned char>& rgba);
 
@@ -19,7 +19,7 @@ void decode_image_rgba8(const unsigned char* bytes, size_t size, uint32_t& width
 bool write_png_rgba8(const std::string& path, uint32_t width, uint32_t height, const unsigned char* rgba,
                      uint32_t stride_bytes);
 
-// Baseline (sequential DCT, Huffman, 8-bit) JPEG, grey or YCbCr, any sampling factors, restart intervals: jpeg_decode.cpp
+// Sequential and progressive DCT JPEG (Huffman, 8-bit), grey or YCbCr, any sampling factors, restart intervals: jpeg_decode.cpp
 void decode_jpeg_rgba8(const unsigned char* bytes, size_t size, uint32_t& width, uint32_t& height, std::vector<unsigned char>& rgba);
 
 std::vector<unsigned char> base64_decode(const std::string& text);
