@@ -279,7 +279,18 @@ class Loader {
       if (comma == std::string::npos) throw std::runtime_error("glTF: bad data URI");
       return base64_decode(uri.substr(comma + 1));
     }
-    const std::string bytes = read_file(base_dir_ + uri);
+    // tinygltf percent-decodes external URIs before opening them ("my%20texture.png", as exporters write names with spaces)
+    std::string decoded;
+    for (size_t i = 0; i < uri.size(); ++i) {
+      auto hex = [](char c) { return c >= '0' && c <= '9' ? c - '0' : (c >= 'a' && c <= 'f' ? c - 'a' + 10 : (c >= 'A' && c <= 'F' ? c - 'A' + 10 : -1)); };
+      if (uri[i] == '%' && i + 2 < uri.size() && hex(uri[i + 1]) >= 0 && hex(uri[i + 2]) >= 0) {
+        decoded.push_back(static_cast<char>(hex(uri[i + 1]) * 16 + hex(uri[i + 2])));
+        i += 2;
+      } else {
+        decoded.push_back(uri[i]);
+      }
+    }
+    const std::string bytes = read_file(base_dir_ + decoded);
     return std::vector<unsigned char>(bytes.begin(), bytes.end());
   }
 

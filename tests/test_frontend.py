@@ -181,6 +181,28 @@ def test_lights_intensity_scale_q9_and_json_gltf_with_data_uri(tmp_path, ptlib):
     assert s.directional_lights[0]["direction"].tolist() == [0, 0, -1] and s.directional_lights[0]["color"].tolist() == [1, 1, 1]
 
 
+def test_external_files_with_percent_encoded_names(tmp_path, ptlib):
+    """.gltf with its buffer and an image in files of their own, named with spaces and written percent-encoded in the JSON
+    (what exporters do; tinygltf decodes the URI before it opens the file)."""
+    from pathtracer_amd.gltf_export import encode_png
+    doc, blob = _one_triangle_doc(extra={
+        "images": [{"uri": "base%20colour%2B1.png"}], "samplers": [{}], "textures": [{"source": 0, "sampler": 0}],
+        "materials": [{"pbrMetallicRoughness": {"baseColorTexture": {"index": 0}}}]})
+    doc["meshes"][0]["primitives"][0]["material"] = 0
+    doc["buffers"][0]["uri"] = "tri%20angle.bin"
+    (tmp_path / "tri angle.bin").write_bytes(blob)
+    tex = np.random.RandomState(2).randint(0, 256, size=(3, 5, 4)).astype(np.uint8)
+    (tmp_path / "base colour+1.png").write_bytes(encode_png(tex))
+    p = tmp_path / "ext.gltf"
+    p.write_text(json.dumps(doc))
+    s = frontend.load_gltf(str(p))
+    assert len(s.triangles) == 1 and len(s.images) == 2 and np.array_equal(s.images[1], tex)
+    doc["buffers"][0]["uri"] = "missing%20file.bin"
+    p.write_text(json.dumps(doc))
+    with pytest.raises(RuntimeError):
+        frontend.load_gltf(str(p))
+
+
 def test_material_defaults_and_emissive_strength(tmp_path, ptlib):
     doc, blob = _one_triangle_doc(extra={"materials": [
         {},
