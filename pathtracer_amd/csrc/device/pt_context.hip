@@ -876,6 +876,16 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
       bool have_prev, drained;
     };
     std::vector<Run> runs;
+    // An error return from inside this block must not leave band streams running: their launches write the caller's buffers, which the
+    // caller may free once the call has failed. (The success path joins through events instead; the host does not wait.)
+    struct Quiesce {
+      std::vector<Run>& runs;
+      bool joined = false;
+      ~Quiesce() {
+        if (!joined)
+          for (Run& r : runs) (void)hipStreamSynchronize(r.s);
+      }
+    } quiesce{runs};
     PT_HIP(ctx, hipEventRecord(ctx->fork_event, stream));
     for (uint32_t c = 0; c < conc && c * band_slots < total_slots; ++c) {
       pt_ctx::Band* band = &ctx->bands[c];
@@ -936,6 +946,7 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
       PT_HIP(ctx, hipStreamWaitEvent(stream, r.done, 0));
       if (r.k > iter_total) iter_total = r.k;
     }
+    quiesce.joined = true;
   } else
   for (uint32_t base = 0; base < total_slots; base += band_slots) {
     f.slot_base = base;
