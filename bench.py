@@ -83,6 +83,8 @@ class HipBackend:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
         self.torch = torch
+        if local_rank >= torch.cuda.device_count():  # a launcher that masks the devices per rank leaves each rank its own as device 0
+            local_rank %= torch.cuda.device_count()
         torch.cuda.set_device(local_rank)
         self.dev = torch.device("cuda", local_rank)
         self.r = Renderer(local_rank)
