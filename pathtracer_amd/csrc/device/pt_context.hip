@@ -740,8 +740,8 @@ hipEvent_t next_kernel_event(pt_ctx* ctx, size_t& used) {
 // no_alloc: the frame's working set is the file-scope scratch array (ctx->scratch_state) and nothing is allocated on the way:
 // path pipeline only (the wavefront pipeline needs request buffers sized by the light count), no per-kernel timing
 // (its events are created on demand), outputs straight into the caller's buffers.
-int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint32_t* primary_dev, hipStream_t stream,
-                 pt_stats* stats_out, bool no_alloc = false) {
+int render_accum_impl(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint32_t* primary_dev, hipStream_t stream,
+                      pt_stats* stats_out, bool no_alloc) {
   if (!ctx->has_scene) return fail(ctx, PT_ERR_NO_SCENE, "pt_upload_scene has not been called");
   const pt_push_constants& pc = p->pc;
   if (!pc.resolution_x || !pc.resolution_y || pc.resolution_x > 65536 || pc.resolution_y > 65536)
@@ -1109,6 +1109,15 @@ int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint
     }
   }
   return PT_OK;
+}
+
+// The call is blocking when it succeeds (it ends with a stream synchronisation); a call that fails half-way must not return while
+// launches it enqueued still write the caller's buffers.
+int render_accum(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev, uint32_t* primary_dev, hipStream_t stream,
+                 pt_stats* stats_out, bool no_alloc = false) {
+  const int rc = render_accum_impl(ctx, p, accum_dev, primary_dev, stream, stats_out, no_alloc);
+  if (rc != PT_OK) (void)hipStreamSynchronize(stream);
+  return rc;
 }
 
 }  // namespace
