@@ -565,8 +565,16 @@ void orc_set_visit_histogram(uint64_t* per_node_counts) { g_visit_hist = per_nod
  * entered) and whether it was an any-hit walk, appended to a caller-owned log. Sizes lane-occupancy models of the kernels. */
 static uint32_t* g_trip_log = NULL;
 static size_t g_trip_cap = 0, g_trip_len = 0;
-void orc_set_trip_log(uint32_t* log, size_t capacity) { g_trip_log = log; g_trip_cap = capacity; g_trip_len = 0; }
+static int g_trip_tagged = 0;      /* two words per traversal: the trips word, then pixel index << 4 | light steps done so far */
+static uint32_t g_trip_tag = 0;
+void orc_set_trip_log(uint32_t* log, size_t capacity) { g_trip_log = log; g_trip_cap = capacity; g_trip_len = 0; g_trip_tagged = 0; }
+void orc_set_trip_log_tagged(uint32_t* log, size_t capacity) { g_trip_log = log; g_trip_cap = capacity; g_trip_len = 0; g_trip_tagged = 1; }
 size_t orc_trip_log_length(void) { return g_trip_len; }
+static void trip_log_push(uint32_t word) {
+  if (!g_trip_log || g_trip_len + (g_trip_tagged ? 2u : 1u) > g_trip_cap) return;
+  g_trip_log[g_trip_len++] = word;
+  if (g_trip_tagged) g_trip_log[g_trip_len++] = g_trip_tag;
+}
 
 static void ray_scene_intersect_ex(shctx* c, const ray_t* ray, isect_t* info, int any_hit) {
   ++c->st.rays;
@@ -582,7 +590,7 @@ static void ray_scene_intersect_ex(shctx* c, const ray_t* ray, isect_t* info, in
       for (uint32_t i = 0; i < node->triangle_count; ++i) {
         ray_triangle_intersect(c, ray, node->left_or_begin + i, info);
         if (any_hit && info->tri_idx != ORC_NO_HIT) {
-          if (g_trip_log && g_trip_len < g_trip_cap) g_trip_log[g_trip_len++] = trips | 0x80000000u;
+          trip_log_push(trips | 0x80000000u);
           return;
         }
       }
@@ -611,7 +619,7 @@ static void ray_scene_intersect_ex(shctx* c, const ray_t* ray, isect_t* info, in
       }
     }
   }
-  if (g_trip_log && g_trip_len < g_trip_cap) g_trip_log[g_trip_len++] = trips | (any_hit ? 0x80000000u : 0u);
+  trip_log_push(trips | (any_hit ? 0x80000000u : 0u));
 }
 
 static void ray_scene_intersect(shctx* c, const ray_t* ray, isect_t* info) {
@@ -859,6 +867,7 @@ static v3 trace(shctx* c, ray_t ray, uint32_t* first_hit) {
     isect_t info;
     info.t = ORC_INFINITY; info.u = info.v = 0.0f; info.tri_idx = ORC_NO_HIT;
     ++c->st.rays_closest;
+    g_trip_tag = (g_trip_tag & ~15u) | light_steps;
     ray_scene_intersect(c, &ray, &info);
     if (first) {
       if (first_hit) *first_hit = info.tri_idx;
@@ -961,6 +970,7 @@ static void shade_pixel(shctx* c, uint32_t x, uint32_t y, uint32_t rank, uint32_
     ray.origin = cam;
     ray.dir = vnormalize(vsub(pixel_center, cam));
     uint32_t fh;
+    g_trip_tag = index << 4;
     v3 rc = trace(c, ray, &fh);
     if (s == s_begin && primary_id) primary_id[index] = fh;
     if (rc.x != rc.x || rc.y != rc.y || rc.z != rc.z) {

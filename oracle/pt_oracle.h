@@ -69,6 +69,7 @@ void orc_microfacet_sample(const float* n, const float* v, float a2, uint32_t* s
 void orc_set_visit_histogram(uint64_t* per_node_counts);
 /* diagnostic, one thread only: trips (inner visits + leaves entered) of every traversal, bit 31 = any-hit walk */
 void orc_set_trip_log(uint32_t* log, size_t capacity);
+void orc_set_trip_log_tagged(uint32_t* log, size_t capacity); /* + a second word per traversal: pixel index << 4 | light steps done */
 size_t orc_trip_log_length(void);
 
 uint32_t orc_triple32(uint32_t x);
