@@ -373,6 +373,8 @@ typedef struct {
   uint32_t* stack;
   int any_hit_shadows; /* ORC_FLAG_ANYHIT_OPAQUE_SHADOW and the scene is provably all-opaque */
   int cull_behind;     /* ORC_FLAG_CULL_BEHIND: skip boxes with t_far < 0 (checker mirror of the HIP path) */
+  int self_first;      /* ORC_FLAG_SELF_FIRST (experiment): any-hit shadow queries test the shading point's own triangle first */
+  uint32_t self_tri;   /* the triangle the current vertex lies on */
   pt_stats st;
 } shctx;
 
@@ -576,6 +578,17 @@ static void trip_log_push(uint32_t word) {
   if (g_trip_tagged) g_trip_log[g_trip_len++] = g_trip_tag;
 }
 
+/* EXPERIMENT (scripts/anyhit_order_model.py): the order an ANY-HIT walk enters two children that are both hit. 0: nearer first
+ * (what the reference's closest-hit walk does and the HIP path mirrors), 1: farther first, 2: the child with the larger box
+ * first, 3: the child with the smaller box first, 4: a leaf before an inner node, else nearer. The answer of an any-hit query
+ * does not depend on it; the work does. */
+static int g_anyhit_order = 0;
+void orc_set_anyhit_order(int order) { g_anyhit_order = order; }
+static float box_area(const pt_packed_bvh_node* n) {
+  float dx = n->aabb_max[0] - n->aabb_min[0], dy = n->aabb_max[1] - n->aabb_min[1], dz = n->aabb_max[2] - n->aabb_min[2];
+  return dx * dy + dy * dz + dz * dx;
+}
+
 static void ray_scene_intersect_ex(shctx* c, const ray_t* ray, isect_t* info, int any_hit) {
   ++c->st.rays;
   const pt_packed_bvh_node* nodes = c->sc->bvh_nodes;
@@ -590,7 +603,7 @@ static void ray_scene_intersect_ex(shctx* c, const ray_t* ray, isect_t* info, in
       for (uint32_t i = 0; i < node->triangle_count; ++i) {
         ray_triangle_intersect(c, ray, node->left_or_begin + i, info);
         if (any_hit && info->tri_idx != ORC_NO_HIT) {
-          trip_log_push(trips | 0x80000000u);
+          trip_log_push(trips | 0xC0000000u); /* bit 30: the walk ended on an accepted triangle */
           return;
         }
       }
@@ -605,7 +618,14 @@ static void ray_scene_intersect_ex(shctx* c, const ray_t* ray, isect_t* info, in
       li = li && (dist_left < info->t);
       ri = ri && (dist_right < info->t);
       if (li && ri) {
-        if (dist_left < dist_right) {
+        int left_first = dist_left < dist_right;
+        if (any_hit && g_anyhit_order) {
+          if (g_anyhit_order == 1) left_first = !left_first;
+          else if (g_anyhit_order == 2) left_first = box_area(left) >= box_area(right);
+          else if (g_anyhit_order == 3) left_first = box_area(left) < box_area(right);
+          else if (g_anyhit_order == 4 && (left->triangle_count > 0) != (right->triangle_count > 0)) left_first = left->triangle_count > 0;
+        }
+        if (left_first) {
           stack[top++] = node->left_or_begin + 1;
           stack[top++] = node->left_or_begin;
         } else {
@@ -639,6 +659,15 @@ static float ray_scene_intersect_with_transparency(shctx* c, ray_t ray, isect_t*
     info->tri_idx = ORC_NO_HIT;
     if (target_tri != ORC_NO_HIT) {
       ray_triangle_intersect(c, &ray, target_tri, info);
+      if (info->tri_idx != ORC_NO_HIT) {
+        ++c->st.rays;
+        ++c->st.rays_shadow_shortcut;
+        return 0.0f;
+      }
+    }
+    if (c->self_first && c->self_tri != ORC_NO_HIT && c->self_tri != target_tri) {
+      /* a light on the far side of the surface: the ray starts NORMAL_DELTA above the triangle it stands on and goes through it */
+      ray_triangle_intersect(c, &ray, c->self_tri, info);
       if (info->tri_idx != ORC_NO_HIT) {
         ++c->st.rays;
         ++c->st.rays_shadow_shortcut;
@@ -874,6 +903,7 @@ static v3 trace(shctx* c, ray_t ray, uint32_t* first_hit) {
       first = 0;
     }
     if (info.tri_idx == ORC_NO_HIT) break;
+    c->self_tri = info.tri_idx;
 
     v3 pos, n;
     float tu, tv;
@@ -1010,6 +1040,7 @@ typedef struct {
   volatile uint32_t* next_row;
   int any_hit_shadows;
   int cull_behind;
+  int self_first;
   pt_stats st;
 } worker_arg;
 
@@ -1021,6 +1052,8 @@ static void* worker_main(void* p) {
   c.pc = &w->rp->pc;
   c.any_hit_shadows = w->any_hit_shadows;
   c.cull_behind = w->cull_behind;
+  c.self_first = w->self_first;
+  c.self_tri = ORC_NO_HIT;
   c.stack = (uint32_t*)malloc(sizeof(uint32_t) * (w->sc->bvh_max_depth + 64)); /* main.comp:263-265 */
   /* work unit: 32 consecutive pixels of a row, so that even a one-row band keeps every thread busy */
   const uint32_t chunks_per_row = (c.pc->resolution_x + 31u) / 32u;
@@ -1080,6 +1113,7 @@ int orc_render_ex(const pt_scene_desc* scene, const pt_render_params* params, ui
     w->primary_id = primary_id_out; w->y_begin = y_begin; w->y_end = y_end; w->next_row = &next_row;
     w->any_hit_shadows = any_hit;
     w->cull_behind = (flags & ORC_FLAG_CULL_BEHIND) != 0;
+    w->self_first = any_hit && (flags & ORC_FLAG_SELF_FIRST) != 0;
     if (num_threads > 1) pthread_create(&th[i], NULL, worker_main, w);
     else worker_main(w);
   }

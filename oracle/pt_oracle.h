@@ -44,6 +44,10 @@ int orc_render(const pt_scene_desc* scene, const pt_render_params* params, uint8
  * the ray origin): no triangle in such a box can pass `t > epsilon`, so images
  * are identical (tests/test_oracle_shader.py checks it); visits/tests shrink. */
 #define ORC_FLAG_CULL_BEHIND 2u
+/* EXPERIMENT (no kernel does this yet; scripts/self_first_model.py): with ORC_FLAG_ANYHIT_OPAQUE_SHADOW on an all-opaque scene, a
+ * shadow query first tests the triangle the shading point lies on. A light behind the surface sends the ray, which starts
+ * NORMAL_DELTA above that triangle, straight through it: one triangle test decides what the walk would find after a full descent. */
+#define ORC_FLAG_SELF_FIRST 4u
 int orc_render_ex(const pt_scene_desc* scene, const pt_render_params* params, uint8_t* rgba8_out,
                   float* accum_out, uint32_t* primary_id_out, pt_stats* stats_out, int num_threads,
                   uint32_t y_begin, uint32_t y_end, uint32_t flags);
@@ -67,10 +71,11 @@ void orc_microfacet_sample(const float* n, const float* v, float a2, uint32_t* s
 
 /* diagnostic: count visits per inner node into per_node_counts[bvh_node_count] (NULL = off) */
 void orc_set_visit_histogram(uint64_t* per_node_counts);
-/* diagnostic, one thread only: trips (inner visits + leaves entered) of every traversal, bit 31 = any-hit walk */
+/* diagnostic, one thread only: trips (inner visits + leaves entered) of every traversal, bit 31 = any-hit walk, bit 30 = it ended on an accepted triangle */
 void orc_set_trip_log(uint32_t* log, size_t capacity);
 void orc_set_trip_log_tagged(uint32_t* log, size_t capacity); /* + a second word per traversal: pixel index << 4 | light steps done */
 size_t orc_trip_log_length(void);
+void orc_set_anyhit_order(int order); /* experiment: entry order of any-hit walks, see pt_oracle.c */
 
 uint32_t orc_triple32(uint32_t x);
 void orc_sincos(float x, float* s, float* c);
