@@ -589,16 +589,39 @@ static float box_area(const pt_packed_bvh_node* n) {
   return dx * dy + dy * dz + dz * dx;
 }
 
+/* EXPERIMENT counters (one thread only; scripts/popcull_model.py): a closest-hit walk compares a child's entry distance with the
+ * closest hit so far when it PUSHES the child; by the time the child is popped the hit may be nearer than that distance. The
+ * reference visits the node anyway. [0] closest-hit pops, [1] of them inner nodes whose entry distance is no longer below the
+ * hit (their children's boxes lie inside theirs, so both are culled: the visit changes nothing), [2] leaves in the same state,
+ * [3] of those leaves, the ones in which a triangle was accepted all the same (would make skipping leaves inexact). */
+static uint64_t g_popcull[4];
+static int g_popcull_on = 0;
+void orc_popcull_counts(uint64_t* out4, int reset_and_enable) {
+  if (out4) memcpy(out4, g_popcull, sizeof g_popcull);
+  if (reset_and_enable >= 0) { memset(g_popcull, 0, sizeof g_popcull); g_popcull_on = reset_and_enable; }
+}
+
 static void ray_scene_intersect_ex(shctx* c, const ray_t* ray, isect_t* info, int any_hit) {
   ++c->st.rays;
   const pt_packed_bvh_node* nodes = c->sc->bvh_nodes;
   uint32_t* stack = c->stack;
+  float dstack[400]; /* entry distances, diagnostic only (trees deeper than 336 levels leave the counters alone) */
+#define ORC_DPUSH(d) do { if (top < 400u) dstack[top] = (d); } while (0)
   uint32_t top = 0;
   uint32_t trips = 0;
+  ORC_DPUSH(-ORC_INFINITY);
   stack[top++] = 0;
   while (top != 0) {
+    const float entry_dist = top <= 400u ? dstack[top - 1] : -ORC_INFINITY;
     const pt_packed_bvh_node* node = &nodes[stack[--top]];
     ++trips;
+    int stale = 0;
+    if (g_popcull_on && !any_hit) {
+      ++g_popcull[0];
+      stale = !(entry_dist < info->t);
+      if (stale) ++g_popcull[node->triangle_count > 0 ? 2 : 1];
+    }
+    const float t_before = info->t;
     if (node->triangle_count > 0) {
       for (uint32_t i = 0; i < node->triangle_count; ++i) {
         ray_triangle_intersect(c, ray, node->left_or_begin + i, info);
@@ -607,6 +630,7 @@ static void ray_scene_intersect_ex(shctx* c, const ray_t* ray, isect_t* info, in
           return;
         }
       }
+      if (stale && info->t != t_before) ++g_popcull[3];
     } else {
       ++c->st.node_visits;
       if (g_visit_hist) ++g_visit_hist[(size_t)(node - nodes)];
@@ -626,16 +650,16 @@ static void ray_scene_intersect_ex(shctx* c, const ray_t* ray, isect_t* info, in
           else if (g_anyhit_order == 4 && (left->triangle_count > 0) != (right->triangle_count > 0)) left_first = left->triangle_count > 0;
         }
         if (left_first) {
-          stack[top++] = node->left_or_begin + 1;
-          stack[top++] = node->left_or_begin;
+          ORC_DPUSH(dist_right); stack[top++] = node->left_or_begin + 1;
+          ORC_DPUSH(dist_left);  stack[top++] = node->left_or_begin;
         } else {
-          stack[top++] = node->left_or_begin;
-          stack[top++] = node->left_or_begin + 1;
+          ORC_DPUSH(dist_left);  stack[top++] = node->left_or_begin;
+          ORC_DPUSH(dist_right); stack[top++] = node->left_or_begin + 1;
         }
       } else if (li) {
-        stack[top++] = node->left_or_begin;
+        ORC_DPUSH(dist_left);  stack[top++] = node->left_or_begin;
       } else if (ri) {
-        stack[top++] = node->left_or_begin + 1;
+        ORC_DPUSH(dist_right); stack[top++] = node->left_or_begin + 1;
       }
     }
   }

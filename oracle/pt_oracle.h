@@ -75,6 +75,7 @@ void orc_set_visit_histogram(uint64_t* per_node_counts);
 void orc_set_trip_log(uint32_t* log, size_t capacity);
 void orc_set_trip_log_tagged(uint32_t* log, size_t capacity); /* + a second word per traversal: pixel index << 4 | light steps done */
 size_t orc_trip_log_length(void);
+void orc_popcull_counts(uint64_t* out4, int reset_and_enable); /* experiment counters, see pt_oracle.c; -1: read only */
 void orc_set_anyhit_order(int order); /* experiment: entry order of any-hit walks, see pt_oracle.c */
 
 uint32_t orc_triple32(uint32_t x);
