@@ -3,20 +3,21 @@
 
 A "step" is one full render of the workload (one pass of the hot path over one frame of
 synthetic input, scene already resident in HBM).  Headline workload = BASELINE.json
-configs[1]: the generated Cornell box with an area light, 1920x1080, sample_count 128
-(121 effective strata, main.comp:596).
+configs[2], the largest configuration defined on ONE GPU: the generated Sponza-class
+textured PBR atrium (~253 k triangles, 44 1024^2 textures), 1920x1080, 256 spp.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL):
-  --split replicate (default, weak scaling): every rank renders the same frame with all its
-      strata from its own decorrelated seed;
-  --split strata (strong scaling of one frame, the split BASELINE configs[3]/[4] are defined
-      on): rank r renders strata [r n^2/N, (r+1) n^2/N) of every pixel.
+  --split strata (default: north_star's partitioning, the split BASELINE configs[3]/[4] are
+      defined on; strong scaling of one frame): rank r renders strata [r n^2/N, (r+1) n^2/N)
+      of every pixel;
+  --split replicate (weak scaling): every rank renders the same frame with all its strata
+      from its own decorrelated seed.
 Either way the float4 accumulators (sum RGB + valid-sample count) are sum-reduced to rank 0
 over xGMI — the path's one exchange step, SURVEY.md §8e — and rank 0 resolves the image.
 Render, reduce and resolve are ordered on ONE explicit (non-default) stream per rank.
 
 At N = 1 the same command also measures the other single-GPU configs of BASELINE.json
-(`--configs`, default cfg1 cube512, cfg3 atrium1080, cfg4's one-GPU frame rocks1080) and
+(`--configs`, default cfg2 cornell1080, cfg1 cube512, cfg4's one-GPU frame rocks1080, cfg5 cornell4k) and
 reports them in the `configs` array of the same JSON line, each with counters, roofline and
 a bounded CPU-oracle sample that is ALSO compared bit for bit with the GPU frame.
 
@@ -55,8 +56,9 @@ WORKLOADS = {
     "cornell_tiny": ("cornell_scene", {}, 96, 54, 16, "test-sized Cornell box (tests/test_bench_script.py); not a bench line"),
 }
 BG = {"atrium1080": (0.5, 0.7, 1.0), "rocks1080": (0.5, 0.7, 1.0), "soup1080": (0.5, 0.7, 1.0)}  # sky; others: README default
-EXTRA_DEFAULT = "cube512,atrium1080,rocks1080,cornell4k"
-EXTRA_STEPS = {"cube512": 20, "atrium1080": 2, "rocks1080": 2, "cornell4k": 1}
+HEADLINE = "atrium1080"
+EXTRA_DEFAULT = "cornell1080,cube512,atrium1080,rocks1080,cornell4k"  # (the headline workload is skipped in this list)
+EXTRA_STEPS = {"cornell1080": 20, "cube512": 20, "atrium1080": 2, "rocks1080": 2, "cornell4k": 1}
 SEED = 0x5EED0000
 COUNTERS = ("paths", "rays", "rays_closest", "rays_shadow_walked", "rays_shadow_shortcut", "node_visits", "tri_tests",
             "hits_shaded", "texture_taps", "shaded_vertices", "nan_samples")
@@ -183,6 +185,8 @@ def roofline_of(sd: dict, scene_in_lds: bool, workload: str, scene_bytes: int, m
                 sd["shade"][k] += sd["shadow"][k]
         names = ("extend", "shade", "shadow")
     kernels = {k: kernel_roofline(k, sd[k], sd["shaded_vertices"]) for k in names if sd[k]["launches"]}
+    if "paths" in kernels and sd.get("merged_walk"):
+        kernels["paths"]["kernel"] = "k_paths_merged"  # scenes in global memory with <= 2 light samples per vertex (pt_stats.merged_walk)
     dom = kernels[max(kernels, key=lambda k: sd[k]["ms"])]
     traffic = traffic_source = None
     traffic_file = os.path.join(ROOT, "profiles", f"traffic_{workload}.json")
@@ -221,19 +225,62 @@ def roofline_of(sd: dict, scene_in_lds: bool, workload: str, scene_bytes: int, m
 
 # --------------------------------------------------------------------------- CPU baseline (the oracle, as checker and yardstick)
 
+def lavapipe_probe() -> str:
+    """SURVEY.md §8d / BASELINE.md: the preferred CPU baseline is the reference's own Vulkan path on Mesa lavapipe. Probe what
+    that needs on this machine and name the first thing that is missing; the number is never made up."""
+    import ctypes.util
+    import glob
+    import shutil
+    if not ctypes.util.find_library("vulkan") and not glob.glob("/usr/lib/*/libvulkan.so*") and not glob.glob("/usr/lib64/libvulkan.so*"):
+        return "unavailable (no Vulkan loader: libvulkan.so.1 not found)"
+    icds = [f for d in ("/usr/share/vulkan/icd.d", "/etc/vulkan/icd.d", "/usr/local/share/vulkan/icd.d") for f in glob.glob(d + "/lvp_icd*.json")]
+    if not icds:
+        return "unavailable (no lavapipe ICD: lvp_icd*.json not found in the Vulkan icd.d directories)"
+    if not shutil.which("glslc"):
+        return "unavailable (no glslc to compile main.comp to SPIR-V)"
+    return "unavailable (loader, lavapipe ICD and glslc found, but the reference's sources and its five submodules do not travel with this repository)"
+
+
+def host_cpu_facts() -> dict:
+    """What the host gives this process: the machine's CPUs, the ones it may run on, and the cgroup quota if one is set."""
+    facts = {"os_cpu_count": os.cpu_count() or 1}
+    try:
+        facts["affinity_cores"] = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        facts["affinity_cores"] = facts["os_cpu_count"]
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        facts["cgroup_quota_cores"] = None if quota == "max" else float(quota) / float(period)
+    except (OSError, ValueError):
+        facts["cgroup_quota_cores"] = None
+    return facts
+
+
 def cpu_baseline(packed, rp, gpu_accum, gpu_ids, seconds_hint: float) -> dict:
     """The CPU oracle (a port of main.comp, oracle/pt_oracle.c) timed on the host cores on a bounded band of rows of
     the same frame, and that band compared bit for bit with the GPU's frame. Reported beside the GPU number; never
-    the target. This leg is the only place bench.py touches oracle/."""
+    the target. This leg is the only place bench.py touches oracle/.
+    `cores` = the threads used: min(16, CPUs this process may run on, cgroup quota). A one-thread calibration on one row of the
+    same frame at 4 spp is reported beside it, so that two boxes' numbers can be told apart (clock and load against thread count)."""
+    import copy
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_lib
     lib = oracle_lib.load()
-    cores = min(16, os.cpu_count() or 1)
+    facts = host_cpu_facts()
+    cores = min(16, facts["affinity_cores"])
+    if facts["cgroup_quota_cores"]:
+        cores = max(1, min(cores, int(facts["cgroup_quota_cores"])))
     w, h = rp.pc.resolution_x, rp.pc.resolution_y
     mid = h // 2
+    small = copy.copy(rp)
+    small.pc = copy.copy(rp.pc)
+    small.pc.sample_count = 4
     t0 = time.perf_counter()
-    oracle_lib.render(lib, packed, rp, threads=cores, rows=(mid, min(mid + 1, h)), want_ids=False)  # warm-up + calibration
+    st1 = oracle_lib.render(lib, packed, small, threads=1, rows=(mid, min(mid + 1, h)), want_ids=False)[3]  # one-thread calibration
+    dt1 = max(time.perf_counter() - t0, 1e-6)
+    t0 = time.perf_counter()
+    oracle_lib.render(lib, packed, rp, threads=cores, rows=(mid, min(mid + 1, h)), want_ids=False)  # warm-up + sizing of the band
     dt = max(time.perf_counter() - t0, 1e-6)
     rows = int(max(1, min(h, seconds_hint / dt)))
     y0 = max(0, mid - rows // 2)
@@ -241,10 +288,16 @@ def cpu_baseline(packed, rp, gpu_accum, gpu_ids, seconds_hint: float) -> dict:
     t0 = time.perf_counter()
     _, o_accum, o_ids, st = oracle_lib.render(lib, packed, rp, threads=cores, rows=(y0, y1), want_ids=True)
     dt = time.perf_counter() - t0
+    value, single = st["rays"] / dt / 1e6, st1["rays"] / dt1 / 1e6
     out = {
-        "value": st["rays"] / dt / 1e6, "unit": "Mrays/s", "mpaths_per_s": st["paths"] / dt / 1e6, "cores": cores,
+        "value": value, "unit": "Mrays/s", "mpaths_per_s": st["paths"] / dt / 1e6, "cores": cores,
         "kind": "port", "seconds": dt,
         "sample": f"rows {y0}..{y1} of {h} of the same frame ({st['paths']} paths, {st['rays']} rays), oracle/pt_oracle.c, {cores} threads",
+        "host": facts, "threads": cores,
+        "single_thread": {"value": single, "unit": "Mrays/s", "seconds": dt1,
+                          "sample": f"row {mid} of the same frame at 4 spp ({st1['rays']} rays), 1 thread"},
+        "parallel_speedup": value / single if single > 0 else None,
+        "lavapipe": lavapipe_probe(),
     }
     if gpu_accum is not None:
         ga = gpu_accum.reshape(h, w, 4)[y0:y1].view(np.uint32)
@@ -343,6 +396,16 @@ def run_workload(be, name: str, steps: int, warmup: int, world: int, rank: int, 
         step(want_ids=True, collective=False)
         frame = be.host_frame()
     last = stats.as_dict()
+    reduced = None
+    if collectives and split == "strata" and world > 1:
+        # strata split: no rank holds the frame on its own, and rank r > 0 draws from its own stream family, so the sum cannot be
+        # compared with a one-GPU digest. What must hold for the REDUCED frame is checked instead (below): every stratum of every
+        # pixel arrived exactly once (valid + dropped samples == n^2), radiance within the clamp, counters summed over the ranks.
+        step(want_ids=False, collective=True)
+        nan_total = torch.tensor([float(stats.nan_samples), float(stats.paths)], dtype=torch.float64, device=be.tensor_device)
+        dist.all_reduce(nan_total, op=dist.ReduceOp.SUM)
+        if rank == 0:
+            reduced = (be.host_frame(), int(nan_total[0]), int(nan_total[1]))
     if collectives:
         dist.barrier()
     if rank != 0:
@@ -381,6 +444,12 @@ def run_workload(be, name: str, steps: int, warmup: int, world: int, rank: int, 
             wf["algorithmic_gbs"] = by / dev_s / 1e9
             wf["hbm_frac"] = by / dev_s / 1e9 / HBM_PEAK_GBS
         out["roofline"]["whole_frame"] = wf
+    if reduced is not None:
+        (r_accum, _, r_rgba), nan_sum, path_sum = reduced
+        valid = r_accum[:, 3]
+        out["reduced_frame_properties_ok"] = bool(np.isfinite(r_accum).all() and (r_accum[:, :3] >= 0).all() and (r_accum[:, :3] <= 10.0 * eff).all()
+                                                  and (valid <= eff).all() and int((eff - valid).sum()) == nan_sum
+                                                  and path_sum == pixels * eff and (r_rgba[:, 3] == 255).all())
     if frame is not None:
         accum, ids, rgba = frame
         out["_frame"] = frame
@@ -388,14 +457,18 @@ def run_workload(be, name: str, steps: int, warmup: int, world: int, rank: int, 
         if name == "cornell1080":
             gold_file = os.path.join(ROOT, "tests", "golden", "cfg2_full_digest.json")
         if os.path.exists(gold_file) and not spp_override:
-            # the oracle's SHA-256 of this WHOLE frame, computed on the CPU and committed (tests/golden/make_*_digest.py)
+            # the oracle's SHA-256 of this frame at its own sample count, computed on the CPU and committed (tests/golden/make_*_digest.py):
+            # the whole frame with its work counters (cfg2), or a band of rows of it (cfg3 / cfg4: the oracle needs hours for the frame)
             gold = json.load(open(gold_file))
             same_job = (gold["width"], gold["height"], gold["sample_count"], gold["seed"]) == (width, height, spp, rp.pc.seed)
-            ok = (same_job and hashlib.sha256(accum.tobytes() + ids.tobytes()).hexdigest() == gold["sha256_accum_then_ids"]
-                  and hashlib.sha256(rgba.tobytes()).hexdigest() == gold["sha256_rgba8"]
-                  and all(int(last[k]) == gold["counters"][k] for k in gold["counters"]))
+            y0, y1 = gold.get("rows", (0, height))
+            band = lambda a: np.ascontiguousarray(a.reshape(height, width, -1)[y0:y1])
+            ok = (same_job and hashlib.sha256(band(accum).tobytes() + band(ids).tobytes()).hexdigest() == gold["sha256_accum_then_ids"]
+                  and hashlib.sha256(band(rgba).tobytes()).hexdigest() == gold["sha256_rgba8"]
+                  and all(int(last[k]) == gold["counters"][k] for k in gold.get("counters", {})))
             out["frame_verified"] = bool(ok)
             out["frame_verified_against"] = os.path.relpath(gold_file, ROOT)
+            out["frame_verified_rows"] = [int(y0), int(y1)]
         valid = accum[:, 3]
         out["frame_properties_ok"] = bool(np.isfinite(accum).all() and (accum[:, :3] >= 0).all() and (accum[:, :3] <= 10.0 * eff).all()
                                           and (valid <= eff).all() and int((eff - valid).sum()) == last["nan_samples"]
@@ -404,6 +477,7 @@ def run_workload(be, name: str, steps: int, warmup: int, world: int, rank: int, 
             progress(f"{name}: timing the CPU oracle on a band of rows (and checking the GPU frame against it)")
             rp.flags = 0
             out["cpu_baseline"] = cpu_baseline(packed, rp, accum, ids, baseline_seconds)
+            progress(f"{name}: lavapipe baseline: {out['cpu_baseline']['lavapipe']}; CPU oracle on {out['cpu_baseline']['threads']} threads instead")
     return out
 
 
@@ -464,9 +538,10 @@ def main(argv=None, backend_factory=None) -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="cornell1080", choices=sorted(WORKLOADS))
-    ap.add_argument("--split", default="replicate", choices=("replicate", "strata"),
-                    help="N > 1: every rank all strata from its own seed (weak scaling) or the strata divided over ranks (strong scaling)")
+    ap.add_argument("--workload", default=HEADLINE, choices=sorted(WORKLOADS))
+    ap.add_argument("--split", default="strata", choices=("strata", "replicate"),
+                    help="N > 1: the strata of every pixel divided over the ranks (north_star's partitioning; strong scaling of one frame) "
+                         "or every rank all strata from its own seed (weak scaling)")
     ap.add_argument("--configs", default=EXTRA_DEFAULT,
                     help="N = 1: further single-GPU configs measured by the same command, comma separated ('none' to skip)")
     ap.add_argument("--spp", type=int, default=0, help="override sample_count (dev only; invalidates the headline)")
@@ -527,7 +602,7 @@ def main(argv=None, backend_factory=None) -> None:
             "dtype": "f32", "data": "synthetic", "config": cfg,
         }
         for k in ("counters", "ray_mix", "reduce_ms_per_step", "roofline", "kernels", "frame_verified", "frame_verified_against",
-                  "frame_properties_ok", "cpu_baseline"):
+                  "frame_verified_rows", "frame_properties_ok", "reduced_frame_properties_ok", "cpu_baseline"):
             if k in head:
                 out[k] = head[k]
         if fast:

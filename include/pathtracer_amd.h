@@ -232,6 +232,9 @@ typedef struct pt_stats {
   double   reduce_ms;            /* device group (pt_create_multi): time of the RCCL sum-reduce of the accumulators */
   uint64_t scene_in_lds;         /* 1: the scene was small enough to be staged whole in every workgroup's LDS
                                     (its fetches are LDS reads, not HBM traffic: the render is VALU-bound)      */
+  uint64_t merged_walk;          /* 1: the path kernel was k_paths_merged (scene in global memory, at most two light samples
+                                    per vertex): a vertex's shadow walks ride with the next closest-hit walk; all traversal
+                                    work is then counted in the `extend` slice                                   */
 } pt_stats;
 
 #define PT_FLAG_TIME_KERNELS 1u /* bracket every kernel with HIP events (serialises; for profiling) */
@@ -289,9 +292,11 @@ PT_API int pt_render(pt_ctx* ctx, const pt_render_params* params,
 PT_API int pt_render_accum_device(pt_ctx* ctx, const pt_render_params* params,
                                   float* accum_dev, uint32_t* primary_id_dev,
                                   void* stream, pt_stats* stats_out);
-/* pt_render_accum_device for callers that cannot allocate device memory (code under HIP
- * graph capture, tight serving loops, harnesses that forbid hipMalloc). NO COUNTERPART IN
- * THE REFERENCE. Same arguments, same results bit for bit, but the frame's working set
+/* pt_render_accum_device for callers that cannot allocate device memory (tight serving
+ * loops, harnesses that forbid hipMalloc, processes whose memory pool is handed out at
+ * start-up). NO COUNTERPART IN THE REFERENCE. Like pt_render_accum_device the call is
+ * HOST-BLOCKING (it polls the live-slot count and ends with a stream synchronisation), so
+ * it must not be made on a stream that is being captured into a HIP graph. Same arguments, same results bit for bit, but the frame's working set
  * (per-slot path state, slot queues, queue counters, work-counter table) lives in a fixed
  * file-scope device array of the library (~26 MiB per GPU, held until the process ends)
  * instead of hipMalloc'd buffers, and nothing is allocated or freed on the way (no

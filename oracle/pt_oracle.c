@@ -373,8 +373,11 @@ typedef struct {
   uint32_t* stack;
   int any_hit_shadows; /* ORC_FLAG_ANYHIT_OPAQUE_SHADOW and the scene is provably all-opaque */
   int cull_behind;     /* ORC_FLAG_CULL_BEHIND: skip boxes with t_far < 0 (checker mirror of the HIP path) */
-  int self_first;      /* ORC_FLAG_SELF_FIRST (experiment): any-hit shadow queries test the shading point's own triangle first */
+  int self_first;      /* ORC_FLAG_SELF_FIRST: any-hit shadow queries test the shading point's own triangle first (checker mirror of the HIP path) */
+  int span_order;      /* ORC_FLAG_ANYHIT_SPAN_ORDER: any-hit walks enter the child the ray stays inside longer first (checker mirror of the HIP path) */
   uint32_t self_tri;   /* the triangle the current vertex lies on */
+  const uint8_t* mat_opaque; /* ORC_FLAG_OPAQUE_TRIANGLES: per material, 1 = provably alpha == 1.0 (checker mirror of the HIP path), else NULL */
+  int in_shadow_walk;  /* diagnostic (trip log): the traversal belongs to ray_scene_intersect_with_transparency */
   pt_stats st;
 } shctx;
 
@@ -420,6 +423,7 @@ static v3 sample_triangle(shctx* c) {
 }
 
 /* main.comp:169-185 */
+static __thread float g_last_t_far; /* experiment switches only (orc_set_anyhit_order >= 5, one thread): t_far of the last box test */
 static int ray_aabb_intersect(const ray_t* ray, const float* bmin, const float* bmax, float* t, int cull_behind) {
   v3 inv_dir = V(1.0f / ray->dir.x, 1.0f / ray->dir.y, 1.0f / ray->dir.z);
   v3 t_min = vmul(inv_dir, vsub(v3from(bmin), ray->origin));
@@ -429,6 +433,7 @@ static int ray_aabb_intersect(const ray_t* ray, const float* bmin, const float* 
   float t_near = gmax(gmax(t1.x, t1.y), t1.z);
   float t_far = gmin(gmin(t2.x, t2.y), t2.z);
   *t = t_near;
+  g_last_t_far = t_far;
   if (cull_behind && t_far < 0.0f) return 0; /* not in the reference: see ORC_FLAG_CULL_BEHIND */
   return t_near <= t_far;
 }
@@ -507,12 +512,16 @@ static v4 sample_texture(shctx* c, int32_t index, float s, float t) {
   int32_t x0 = wrap_coord(i0, W, smp->wrap_s), x1 = wrap_coord(i0 + 1, W, smp->wrap_s);
   int32_t y0 = wrap_coord(j0, H, smp->wrap_t), y1 = wrap_coord(j0 + 1, H, smp->wrap_t);
   v4 t00 = texel(img, x0, y0), t10 = texel(img, x1, y0), t01 = texel(img, x0, y1), t11 = texel(img, x1, y1);
-  float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+  /* tau = lerp(b, lerp(a, t00, t10), lerp(a, t01, t11)), lerp(w, x, y) = x + w * (y - x): the form Mesa llvmpipe's float path
+   * evaluates (lp_build_lerp_2d), and like every hardware filter (fixed-point weights that sum to one) it returns a constant
+   * for four equal texels — the alpha of an all-opaque texture comes out as exactly 1.0, which main.comp:325 and :542 branch on.
+   * (Rounds 1-2 used the weighted sum w00 t00 + w10 t10 + w01 t01 + w11 t11: its float32 weights miss 1.0 for 3.9 % of the
+   * (a, b) pairs, which turned opaque textured walls into alpha = 0.99999994 pass-through surfaces at that rate.) */
   v4 r;
-  r.r = ((w00 * t00.r + w10 * t10.r) + w01 * t01.r) + w11 * t11.r;
-  r.g = ((w00 * t00.g + w10 * t10.g) + w01 * t01.g) + w11 * t11.g;
-  r.b = ((w00 * t00.b + w10 * t10.b) + w01 * t01.b) + w11 * t11.b;
-  r.a = ((w00 * t00.a + w10 * t10.a) + w01 * t01.a) + w11 * t11.a;
+  { float lo = t00.r + a * (t10.r - t00.r), hi = t01.r + a * (t11.r - t01.r); r.r = lo + b * (hi - lo); }
+  { float lo = t00.g + a * (t10.g - t00.g), hi = t01.g + a * (t11.g - t01.g); r.g = lo + b * (hi - lo); }
+  { float lo = t00.b + a * (t10.b - t00.b), hi = t01.b + a * (t11.b - t01.b); r.b = lo + b * (hi - lo); }
+  { float lo = t00.a + a * (t10.a - t00.a), hi = t01.a + a * (t11.a - t01.a); r.a = lo + b * (hi - lo); }
   return r;
 }
 
@@ -626,7 +635,7 @@ static void ray_scene_intersect_ex(shctx* c, const ray_t* ray, isect_t* info, in
       for (uint32_t i = 0; i < node->triangle_count; ++i) {
         ray_triangle_intersect(c, ray, node->left_or_begin + i, info);
         if (any_hit && info->tri_idx != ORC_NO_HIT) {
-          trip_log_push(trips | 0xC0000000u); /* bit 30: the walk ended on an accepted triangle */
+          trip_log_push(trips | 0xE0000000u); /* bit 30: the walk ended on an accepted triangle */
           return;
         }
       }
@@ -638,16 +647,33 @@ static void ray_scene_intersect_ex(shctx* c, const ray_t* ray, isect_t* info, in
       const pt_packed_bvh_node* right = &nodes[node->left_or_begin + 1];
       float dist_left, dist_right;
       int li = ray_aabb_intersect(ray, left->aabb_min, left->aabb_max, &dist_left, c->cull_behind);
+      const float far_left = g_last_t_far;
       int ri = ray_aabb_intersect(ray, right->aabb_min, right->aabb_max, &dist_right, c->cull_behind);
+      const float far_right = g_last_t_far;
       li = li && (dist_left < info->t);
       ri = ri && (dist_right < info->t);
       if (li && ri) {
         int left_first = dist_left < dist_right;
+        if (any_hit && c->span_order && !g_anyhit_order) /* the HIP path's any-hit order: the longer stretch of the ray inside the box, from the origin on */
+          left_first = (far_left - gmax(dist_left, 0.0f)) >= (far_right - gmax(dist_right, 0.0f));
         if (any_hit && g_anyhit_order) {
           if (g_anyhit_order == 1) left_first = !left_first;
           else if (g_anyhit_order == 2) left_first = box_area(left) >= box_area(right);
           else if (g_anyhit_order == 3) left_first = box_area(left) < box_area(right);
           else if (g_anyhit_order == 4 && (left->triangle_count > 0) != (right->triangle_count > 0)) left_first = left->triangle_count > 0;
+          else if (g_anyhit_order == 5) left_first = (far_left - gmax(dist_left, 0.0f)) >= (far_right - gmax(dist_right, 0.0f)); /* longer span inside the box first */
+          else if (g_anyhit_order == 6) left_first = (far_left - gmax(dist_left, 0.0f)) < (far_right - gmax(dist_right, 0.0f));
+          else if (g_anyhit_order == 7) left_first = far_left >= far_right; /* larger exit distance first */
+          else if (g_anyhit_order == 9) { /* span relative to the box's extent: the ray that crosses its box more centrally first */
+            float el = (left->aabb_max[0] - left->aabb_min[0]) + (left->aabb_max[1] - left->aabb_min[1]) + (left->aabb_max[2] - left->aabb_min[2]);
+            float er = (right->aabb_max[0] - right->aabb_min[0]) + (right->aabb_max[1] - right->aabb_min[1]) + (right->aabb_max[2] - right->aabb_min[2]);
+            left_first = (far_left - gmax(dist_left, 0.0f)) * er >= (far_right - gmax(dist_right, 0.0f)) * el;
+          }
+          else if (g_anyhit_order == 10) left_first = (far_left - dist_left) >= (far_right - dist_right); /* span without the clamp at the origin */
+          else if (g_anyhit_order == 8) { /* farther first, but a leaf before an inner node */
+            if ((left->triangle_count > 0) != (right->triangle_count > 0)) left_first = left->triangle_count > 0;
+            else left_first = !left_first;
+          }
         }
         if (left_first) {
           ORC_DPUSH(dist_right); stack[top++] = node->left_or_begin + 1;
@@ -663,7 +689,7 @@ static void ray_scene_intersect_ex(shctx* c, const ray_t* ray, isect_t* info, in
       }
     }
   }
-  trip_log_push(trips | (any_hit ? 0x80000000u : 0u));
+  trip_log_push(trips | (any_hit ? 0x80000000u : 0u) | (c->in_shadow_walk ? 0x20000000u : 0u)); /* bit 29: a shadow-walk step */
 }
 
 static void ray_scene_intersect(shctx* c, const ray_t* ray, isect_t* info) {
@@ -699,7 +725,9 @@ static float ray_scene_intersect_with_transparency(shctx* c, ray_t ray, isect_t*
       }
     }
     ++c->st.rays_shadow_walked;
+    c->in_shadow_walk = 1;
     ray_scene_intersect_ex(c, &ray, info, 1);
+    c->in_shadow_walk = 0;
     return info->tri_idx == ORC_NO_HIT ? 1.0f : 0.0f;
   }
   while (step < ORC_MAX_TRANSPARENCY_STEPS) {
@@ -707,8 +735,13 @@ static float ray_scene_intersect_with_transparency(shctx* c, ray_t ray, isect_t*
     info->t = ORC_INFINITY;
     info->tri_idx = ORC_NO_HIT;
     ++c->st.rays_shadow_walked;
+    c->in_shadow_walk = 1;
     ray_scene_intersect(c, &ray, info);
+    c->in_shadow_walk = 0;
     if (info->tri_idx == ORC_NO_HIT) break;
+    /* checker mirror of the HIP path: a closest hit on a triangle whose material is PROVABLY opaque returns 0 (main.comp:325)
+     * without fetching its attributes, material and texture — same result, fewer hits_shaded / texture_taps */
+    if (c->mat_opaque && c->mat_opaque[c->sc->packed_vertex_data[3 * (size_t)info->tri_idx].material_index]) return 0.0f;
 
     v3 pos, n;
     float tu, tv;
@@ -920,7 +953,7 @@ static v3 trace(shctx* c, ray_t ray, uint32_t* first_hit) {
     isect_t info;
     info.t = ORC_INFINITY; info.u = info.v = 0.0f; info.tri_idx = ORC_NO_HIT;
     ++c->st.rays_closest;
-    g_trip_tag = (g_trip_tag & ~15u) | light_steps;
+    if (g_trip_log && g_trip_tagged) g_trip_tag = (g_trip_tag & ~15u) | light_steps; /* diagnostic, one thread only */
     ray_scene_intersect(c, &ray, &info);
     if (first) {
       if (first_hit) *first_hit = info.tri_idx;
@@ -1024,7 +1057,7 @@ static void shade_pixel(shctx* c, uint32_t x, uint32_t y, uint32_t rank, uint32_
     ray.origin = cam;
     ray.dir = vnormalize(vsub(pixel_center, cam));
     uint32_t fh;
-    g_trip_tag = index << 4;
+    if (g_trip_log && g_trip_tagged) g_trip_tag = index << 4;
     v3 rc = trace(c, ray, &fh);
     if (s == s_begin && primary_id) primary_id[index] = fh;
     if (rc.x != rc.x || rc.y != rc.y || rc.z != rc.z) {
@@ -1065,6 +1098,8 @@ typedef struct {
   int any_hit_shadows;
   int cull_behind;
   int self_first;
+  int span_order;
+  const uint8_t* mat_opaque;
   pt_stats st;
 } worker_arg;
 
@@ -1077,6 +1112,8 @@ static void* worker_main(void* p) {
   c.any_hit_shadows = w->any_hit_shadows;
   c.cull_behind = w->cull_behind;
   c.self_first = w->self_first;
+  c.span_order = w->span_order;
+  c.mat_opaque = w->mat_opaque;
   c.self_tri = ORC_NO_HIT;
   c.stack = (uint32_t*)malloc(sizeof(uint32_t) * (w->sc->bvh_max_depth + 64)); /* main.comp:263-265 */
   /* work unit: 32 consecutive pixels of a row, so that even a one-row band keeps every thread busy */
@@ -1095,20 +1132,25 @@ static void* worker_main(void* p) {
 }
 
 /* 1 iff no surface can ever report alpha != 1.0 in the shadow walk: every material has
- * base_color_factor.a == 1 and either no base-colour texture or one that is sampled with
- * the nearest filter from an image whose alpha bytes are all 255 (a bilinear blend of
- * ones need not round to exactly 1.0). Mirrors the rule of pt_upload_scene. */
+ * base_color_factor.a == 1 and either no base-colour texture or one whose image's alpha bytes
+ * are all 255 (nearest: the texel itself; linear: lerps of equal values, x + w * (x - x) == x).
+ * Mirrors the rule of pt_upload_scene. */
+static int material_provably_opaque(const pt_scene_desc* sc, const pt_material* m, uint8_t* image_memo) {
+  if (m->base_color_factor[3] != 1.0f) return 0;
+  if (m->base_color_texture_index == -1) return 1;
+  const int32_t ii = sc->textures[m->base_color_texture_index].image_index;
+  if (image_memo && image_memo[ii]) return image_memo[ii] == 1;
+  const pt_image* im = &sc->images[ii];
+  int opaque = 1;
+  for (size_t k = 0; k < (size_t)im->width * im->height; ++k)
+    if (im->rgba8[4 * k + 3] != 255) { opaque = 0; break; }
+  if (image_memo) image_memo[ii] = opaque ? 1 : 2;
+  return opaque;
+}
+
 int orc_scene_all_opaque(const pt_scene_desc* sc) {
-  for (uint32_t i = 0; i < sc->material_count; ++i) {
-    const pt_material* m = &sc->materials[i];
-    if (m->base_color_factor[3] != 1.0f) return 0;
-    if (m->base_color_texture_index == -1) continue;
-    const pt_texture* t = &sc->textures[m->base_color_texture_index];
-    if (sc->samplers[t->sampler_index].mag_filter != PT_FILTER_NEAREST) return 0;
-    const pt_image* im = &sc->images[t->image_index];
-    for (size_t k = 0; k < (size_t)im->width * im->height; ++k)
-      if (im->rgba8[4 * k + 3] != 255) return 0;
-  }
+  for (uint32_t i = 0; i < sc->material_count; ++i)
+    if (!material_provably_opaque(sc, &sc->materials[i], NULL)) return 0;
   return 1;
 }
 
@@ -1128,6 +1170,13 @@ int orc_render_ex(const pt_scene_desc* scene, const pt_render_params* params, ui
   if (num_threads > 256) num_threads = 256;
   volatile uint32_t next_row = 0; /* next 32-pixel chunk of the band */
   const int any_hit = (flags & ORC_FLAG_ANYHIT_OPAQUE_SHADOW) && orc_scene_all_opaque(scene);
+  uint8_t* mat_opaque = NULL;
+  if ((flags & ORC_FLAG_OPAQUE_TRIANGLES) && !any_hit) {
+    uint8_t* memo = (uint8_t*)calloc(scene->image_count ? scene->image_count : 1, 1);
+    mat_opaque = (uint8_t*)calloc(scene->material_count, 1);
+    for (uint32_t i = 0; i < scene->material_count; ++i) mat_opaque[i] = (uint8_t)material_provably_opaque(scene, &scene->materials[i], memo);
+    free(memo);
+  }
   pthread_t th[256];
   worker_arg args[256];
   for (int i = 0; i < num_threads; ++i) {
@@ -1138,6 +1187,8 @@ int orc_render_ex(const pt_scene_desc* scene, const pt_render_params* params, ui
     w->any_hit_shadows = any_hit;
     w->cull_behind = (flags & ORC_FLAG_CULL_BEHIND) != 0;
     w->self_first = any_hit && (flags & ORC_FLAG_SELF_FIRST) != 0;
+    w->span_order = any_hit && (flags & ORC_FLAG_ANYHIT_SPAN_ORDER) != 0;
+    w->mat_opaque = mat_opaque;
     if (num_threads > 1) pthread_create(&th[i], NULL, worker_main, w);
     else worker_main(w);
   }
@@ -1157,6 +1208,7 @@ int orc_render_ex(const pt_scene_desc* scene, const pt_render_params* params, ui
     total.rays_shadow_walked += args[i].st.rays_shadow_walked;
     total.rays_shadow_shortcut += args[i].st.rays_shadow_shortcut;
   }
+  free(mat_opaque);
   if (stats_out) *stats_out = total;
   return 0;
 }

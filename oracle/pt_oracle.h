@@ -44,10 +44,21 @@ int orc_render(const pt_scene_desc* scene, const pt_render_params* params, uint8
  * the ray origin): no triangle in such a box can pass `t > epsilon`, so images
  * are identical (tests/test_oracle_shader.py checks it); visits/tests shrink. */
 #define ORC_FLAG_CULL_BEHIND 2u
-/* EXPERIMENT (no kernel does this yet; scripts/self_first_model.py): with ORC_FLAG_ANYHIT_OPAQUE_SHADOW on an all-opaque scene, a
- * shadow query first tests the triangle the shading point lies on. A light behind the surface sends the ray, which starts
- * NORMAL_DELTA above that triangle, straight through it: one triangle test decides what the walk would find after a full descent. */
+/* ORC_FLAG_SELF_FIRST mirrors the HIP path's second shadow-ray shortcut (with ORC_FLAG_ANYHIT_OPAQUE_SHADOW on an all-opaque scene):
+ * a shadow query first tests the triangle the shading point lies on. A light behind the surface sends the ray, which starts
+ * NORMAL_DELTA above that triangle, straight through it: one triangle test decides what the walk would find after a full descent
+ * (scripts/self_first_model.py: 51 % of the 5 M-triangle rocks' shadow rays). Any accepted triangle decides, so images are identical. */
 #define ORC_FLAG_SELF_FIRST 4u
+/* ORC_FLAG_ANYHIT_SPAN_ORDER mirrors the order in which the HIP path's any-hit walks enter two children that are both hit: the one
+ * in whose box the ray stays longer (t_far - max(t_near, 0)) first, the left one on a tie. A yes / no query's answer does not depend
+ * on the order (only closest-hit walks owe the reference theirs, Q14); the work does (scripts/anyhit_order_model.py: -8.6 % of all
+ * node visits on the rocks, -10.7 % on the 1 M-triangle soup). */
+#define ORC_FLAG_ANYHIT_SPAN_ORDER 8u
+/* ORC_FLAG_OPAQUE_TRIANGLES mirrors the HIP path's shortcut for scenes that are NOT all-opaque: when the closest hit of a shadow-walk
+ * step lies on a triangle whose material is provably opaque (base_color_factor.a == 1 and no base-colour texture or one whose alpha
+ * bytes are all 255), the walk returns 0 (main.comp:325) without get_interpolated_data, the material fetch and the texture tap: the
+ * same result with fewer hits_shaded / texture_taps. */
+#define ORC_FLAG_OPAQUE_TRIANGLES 16u
 int orc_render_ex(const pt_scene_desc* scene, const pt_render_params* params, uint8_t* rgba8_out,
                   float* accum_out, uint32_t* primary_id_out, pt_stats* stats_out, int num_threads,
                   uint32_t y_begin, uint32_t y_end, uint32_t flags);

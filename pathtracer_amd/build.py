@@ -21,7 +21,7 @@ OBJ_DIR = os.path.join(HERE, "build")  # intermediate objects (git-ignored)
 # to identical bits.  IEEE-correct fp32 divide and sqrt are hipcc's defaults for HIP.
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fvisibility=hidden",
           "-Wall", "-Wno-unused-function", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(CSRC, "device")]
-DEVICE_SRC = [os.path.join(CSRC, "device", f) for f in ("pt_kernels.hip", "pt_context.hip", "pt_sort.hip")]
+DEVICE_SRC = [os.path.join(CSRC, "device", f) for f in ("pt_kernels.hip", "pt_context.hip")]
 FAST_SRC = os.path.join(CSRC, "device", "pt_kernels_fast.hip")
 RS_SRC = os.path.join(CSRC, "device", "pt_kernels_rs.hip")  # the traversal kernels with (record, side) stack entries
 HOST_SRC = [os.path.join(CSRC, "host", f) for f in ("bvh_builder.cpp", "scene_pack.cpp")]

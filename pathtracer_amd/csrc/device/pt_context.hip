@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -57,7 +58,8 @@ static_assert(kScratchBytes <= (32ull << 20), "scratch is meant to stay modest")
 static __device__ __align__(256) unsigned char scratch[kScratchBytes];
 
 constexpr int kMaxDevices = 64;
-unsigned char* g_scratch_ptr[kMaxDevices] = {};  // per device: device address of that GPU's copy of `scratch`
+unsigned char* g_scratch_ptr[kMaxDevices] = {};  // per device: device address of that GPU's copy of `scratch` (under g_scratch_mutex)
+std::mutex g_scratch_mutex;                      // pt_create may run on several host threads at once
 
 // RCCL, loaded on demand (pt_create_multi): one communicator per GPU of a single-process device group, used for exactly one
 // collective per frame — the sum-reduce of the float4 accumulators to the group's first GPU. No link-time
@@ -76,12 +78,18 @@ struct RcclApi {
 RcclApi& rccl() {
   static RcclApi api;
   if (api.lib || !api.error.empty()) return api;
+  // PT_RCCL_LIB names the library to load instead (a site's own build; the CPU suite points it at a missing file to see the error path)
+  const char* override_name = std::getenv("PT_RCCL_LIB");
+  std::string last_error;
   for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-    api.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+    api.lib = dlopen(override_name ? override_name : name, RTLD_NOW | RTLD_LOCAL);
     if (api.lib) break;
+    const char* e = dlerror();  // returns the message ONCE and clears it
+    last_error = e ? e : "dlopen failed";
+    if (override_name) break;
   }
   if (!api.lib) {
-    api.error = std::string("librccl.so not found: ") + (dlerror() ? dlerror() : "dlopen failed");
+    api.error = std::string("librccl.so not found: ") + last_error;
     return api;
   }
   auto sym = [&](const char* n) {
@@ -145,14 +153,12 @@ struct pt_ctx {
   uint32_t lds_stack = 16;          // PT_LDS_STACK: traversal-stack rows in LDS per lane for scenes in global memory (0 = the whole depth).
                                     // 16 rows + private-memory overflow: the 4.7 M-triangle rocks (depth 33) go from 4 to 7 k_extend waves
                                     // per SIMD (-21 % k_extend time) and k_paths +5 %; shallower trees are unaffected (measured)
+  bool merged = true;               // PT_MERGED=0: scenes in global memory with at most two light samples per vertex run k_paths (shadow walks in
+                                    // their own phase) instead of k_paths_merged (a vertex's shadow walks ride with the next closest-hit walk)
+  uint32_t merged_lds_stack = 9;    // PT_MERGED_LDS_STACK: LDS stack rows per lane of k_paths_merged, deeper rows in private memory. 36 B + 80 B of stash per
+                                    // lane keep 20 waves per CU inside the 160 KB (measured, rocks / atrium Mrays/s: 4 rows 1461 / 1961, 6: 1529 / 2025,
+                                    // 8: 1601 / 2038, 9: 1623 / 2040, 10: 1544 / 1933, 11: 1549 / 1933, 16: fewer waves fit)
   bool child_entries = true;        // PT_CHILD_ENTRIES=0: traversal-stack entries as (record, side) even where the scene allows (ref << 7 | cnt)
-  uint32_t sort_rays = 0;           // EXPERIMENT PT_SORT_RAYS: 1 = origin-major key, 2 = octant-major (wavefront pipeline only)
-  uint32_t sort_bits = 6;           // PT_SORT_BITS: origin cell bits per axis
-  uint32_t sort_shadow = 0;         // PT_SORT_SHADOW: also re-order the shadow queue
-  float scene_lo[3] = {0, 0, 0}, scene_hi[3] = {1, 1, 1};
-  uint32_t *sort_keys[2] = {nullptr, nullptr}, *sort_queue_out = nullptr, *sort_shadow_out = nullptr;
-  void* sort_temp = nullptr;
-  size_t sort_temp_bytes = 0;
   uint32_t* host_counts = nullptr;  // pinned: [0..1] polled live-slot counts, from byte 64 on the work-counter totals
   unsigned char* scratch = nullptr; // this device's copy of the file-scope scratch array (pt_render_accum_device_noalloc)
   pt_dev_state scratch_state{};     // the scratch carved into the per-slot buffers of a frame of kNoAllocSlots slots
@@ -362,16 +368,6 @@ int ensure_state(pt_ctx* ctx, uint32_t slots, uint32_t lights, uint32_t pixels) 
   st.stat_rows = slots / 64 * 2 + 16;  // >= the largest grid (64-thread blocks, rounded up to a multiple of 8)
   ALLOC(st.stats, static_cast<size_t>(PT_K_COUNT) * st.stat_rows * PT_ST_WORDS);
   ALLOC(st.stat_totals, static_cast<size_t>(PT_K_COUNT) * PT_ST_WORDS);
-  if (ctx->sort_rays) {
-    ALLOC(ctx->sort_keys[0], slots);
-    ALLOC(ctx->sort_keys[1], slots);
-    ALLOC(ctx->sort_queue_out, slots);
-    ALLOC(ctx->sort_shadow_out, slots);
-    ctx->sort_temp_bytes = ptd::sort_temp_bytes(slots);
-    unsigned char* tmp = nullptr;
-    if ((rc = dev_alloc(ctx, ctx->state_bufs, &tmp, ctx->sort_temp_bytes)) != PT_OK) return rc;
-    ctx->sort_temp = tmp;
-  }
   ALLOC(ctx->accum_out, pixels);
   ALLOC(ctx->primary_out, pixels);
   ALLOC(ctx->rgba8_out, pixels);
@@ -445,11 +441,11 @@ extern "C" pt_ctx* pt_create(int device) {
   if (const char* e = std::getenv("PT_SPLIT_SHADOW")) ctx->split_shadow = std::strtoul(e, nullptr, 10) != 0;
   if (const char* e = std::getenv("PT_TAIL_ENTRIES")) ctx->tail_entries = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   if (const char* e = std::getenv("PT_LDS_STACK")) ctx->lds_stack = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
+  if (ctx->lds_stack > 64) ctx->lds_stack = 64;  // 256 threads x 64 rows x 4 B = the 64 KiB a workgroup may ask for
   if (const char* e = std::getenv("PT_CHILD_ENTRIES")) ctx->child_entries = std::atoi(e) != 0;
-  if (const char* e = std::getenv("PT_SORT_RAYS")) ctx->sort_rays = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
-  if (const char* e = std::getenv("PT_SORT_BITS")) ctx->sort_bits = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
-  if (const char* e = std::getenv("PT_SORT_SHADOW")) ctx->sort_shadow = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
-  if (ctx->sort_bits < 1 || ctx->sort_bits > 9) ctx->sort_bits = 6;
+  if (const char* e = std::getenv("PT_MERGED")) ctx->merged = std::atoi(e) != 0;
+  if (const char* e = std::getenv("PT_MERGED_LDS_STACK")) ctx->merged_lds_stack = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
+  if (ctx->merged_lds_stack > 64) ctx->merged_lds_stack = 64;
   if (const char* e = std::getenv("PT_CONCURRENT_BANDS")) ctx->concurrent_bands = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   if (const char* e = std::getenv("PT_BAND_MIN_TILES")) ctx->band_min_tiles = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   if (ctx->band_min_tiles < 1) ctx->band_min_tiles = 1;
@@ -470,6 +466,7 @@ extern "C" pt_ctx* pt_create(int device) {
   // The no-allocation entry point's scratch: once per device, with that device current (set above), look up where THIS
   // GPU holds its copy of the file-scope array. Only this pointer is ever handed to a kernel, memset or copy.
   if (device < kMaxDevices) {
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
     if (!g_scratch_ptr[device]) {
       void* sym = nullptr;
       const hipError_t se = hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch));
@@ -618,8 +615,43 @@ static int upload_one(pt_ctx* ctx, const pt_scene_desc* s) {
       return rc;
     PT_HIP(ctx, hipStreamSynchronize(ctx->stream));  // rec dies here
   }
-  if ((rc = dev_upload(ctx, ctx->scene_bufs, &d.tri_pos, reinterpret_cast<const float4*>(s->vertex_positions), 3 * ntri)) != PT_OK)
-    return rc;
+  // Triangle positions: the reference's binding 0 (3 x vec4 per triangle) with ONE word of its padding put to use: the w of a
+  // triangle's first vertex is a tag, non-zero when the triangle's material is provably opaque (base_color_factor.a == 1 and no
+  // base-colour texture or one whose image's alpha bytes are all 255: nearest returns the texel, linear lerps equal values). The
+  // traversal has that quad in registers anyway, so a shadow walk knows without another fetch that its closest hit returns 0.
+  std::vector<uint8_t> mat_opaque(s->material_count, 0);
+  {
+    std::vector<uint8_t> image_opaque(s->image_count, 0);  // 0 unknown, 1 all alpha bytes 255, 2 not
+    for (uint32_t i = 0; i < s->material_count; ++i) {
+      const pt_material& m = s->materials[i];
+      if (m.base_color_factor[3] != 1.0f) continue;
+      if (m.base_color_texture_index == -1) {
+        mat_opaque[i] = 1;
+        continue;
+      }
+      const int32_t ii = s->textures[m.base_color_texture_index].image_index;
+      if (!image_opaque[ii]) {
+        const pt_image& im = s->images[ii];
+        const size_t n = static_cast<size_t>(im.width) * im.height;
+        image_opaque[ii] = 1;
+        for (size_t k = 0; k < n; ++k)
+          if (im.rgba8[4 * k + 3] != 255) {
+            image_opaque[ii] = 2;
+            break;
+          }
+      }
+      mat_opaque[i] = image_opaque[ii] == 1;
+    }
+  }
+  {
+    std::vector<float> pos(s->vertex_positions, s->vertex_positions + 12 * ntri);
+    for (size_t t = 0; t < ntri; ++t) {
+      const uint32_t tag = mat_opaque[static_cast<uint32_t>(s->packed_vertex_data[3 * t].material_index)] ? 1u : 0u;
+      std::memcpy(&pos[12 * t + 3], &tag, 4);
+    }
+    if ((rc = dev_upload(ctx, ctx->scene_bufs, &d.tri_pos, reinterpret_cast<const float4*>(pos.data()), 3 * ntri)) != PT_OK) return rc;
+    PT_HIP(ctx, hipStreamSynchronize(ctx->stream));  // pos dies here
+  }
 
   // 192-byte vertex triple -> 64-byte attribute record (drops tangent, bitangent, duplicate position: Q15)
   std::vector<float> attr(16 * ntri);
@@ -670,37 +702,16 @@ static int upload_one(pt_ctx* ctx, const pt_scene_desc* s) {
   if ((rc = dev_upload(ctx, ctx->scene_bufs, &d.texels, pool.data(), pool.size())) != PT_OK) return rc;
   if ((rc = dev_upload(ctx, ctx->scene_bufs, &d.textures, trec.data(), trec.size())) != PT_OK) return rc;
 
-  // Provably all-opaque scene: every material has base_color_factor.a == 1 and either no
-  // base-colour texture or one sampled with the nearest filter from an image whose alpha
-  // bytes are all 255 (a bilinear blend of ones need not round to exactly 1.0).
+  // Provably all-opaque scene: every material is (shadow rays may then stop at the first accepted triangle)
   d.all_opaque = 1;
-  for (uint32_t i = 0; i < s->material_count && d.all_opaque; ++i) {
-    const pt_material& m = s->materials[i];
-    if (m.base_color_factor[3] != 1.0f) d.all_opaque = 0;
-    else if (m.base_color_texture_index != -1) {
-      const pt_texture& t = s->textures[m.base_color_texture_index];
-      if (s->samplers[t.sampler_index].mag_filter != PT_FILTER_NEAREST) d.all_opaque = 0;
-      else {
-        const pt_image& im = s->images[t.image_index];
-        const size_t n = static_cast<size_t>(im.width) * im.height;
-        for (size_t k = 0; k < n; ++k)
-          if (im.rgba8[4 * k + 3] != 255) {
-            d.all_opaque = 0;
-            break;
-          }
-      }
-    }
-  }
+  for (uint32_t i = 0; i < s->material_count; ++i)
+    if (!mat_opaque[i]) d.all_opaque = 0;
   d.any_texture = 0;
   for (uint32_t i = 0; i < s->material_count; ++i) {
     const pt_material& m = s->materials[i];
     if (m.base_color_texture_index != -1 || m.metallic_roughness_texture_index != -1 || m.emissive_texture_index != -1 ||
         m.occlusion_texture_index != -1)
       d.any_texture = 1;
-  }
-  for (int k = 0; k < 3; ++k) {  // scene bounds for the ray-sorting experiment: the root's box or the union of its children
-    ctx->scene_lo[k] = s->bvh_nodes[0].aabb_min[k];
-    ctx->scene_hi[k] = s->bvh_nodes[0].aabb_max[k];
   }
   d.directional_light_count = s->directional_light_count;
   d.point_light_count = s->point_light_count;
@@ -786,8 +797,13 @@ int render_accum_impl(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev,
                                              : 0u;
   if (256u * sc.stack_entries * 4u + scene_lds > 65536u) sc.scene_in_lds = 0;  // deep tree: the stack needs the LDS
   uint32_t trace_block = (256u * sc.stack_entries * 4u <= 65536u) ? 256u : 64u;
-  if (!sc.scene_in_lds && ctx->lds_stack && ctx->lds_stack < sc.stack_entries && sc.stack_entries <= ctx->lds_stack + 48u) {
-    sc.lds_stack_levels = ctx->lds_stack;  // short LDS stack, the rest of the depth in private memory (kDeepLevels = 48 rows)
+  const int pipeline = no_alloc ? 0 : ctx->pipeline;
+  // k_paths_merged: the path pipeline on a scene read from global memory whose vertices draw at most two light samples (its two stash slots)
+  const bool merged = pipeline == 0 && ctx->merged && !sc.scene_in_lds && n_lights <= 2u;
+  const uint32_t lds_stack = merged ? ctx->merged_lds_stack : ctx->lds_stack;
+  static_assert(PT_DEEP_LEVELS == 48, "the private overflow rows of traverse() (pt_kernels.hip, kDeepLevels) bound the inequality below");
+  if (!sc.scene_in_lds && lds_stack && lds_stack < sc.stack_entries && sc.stack_entries <= lds_stack + PT_DEEP_LEVELS) {
+    sc.lds_stack_levels = lds_stack;  // short LDS stack, the rest of the depth in private memory (kDeepLevels = 48 rows)
     trace_block = 256u;
   }
   // The traversal kernels exist in two compilations (pt_kernels.hip, PT_STACK_CHILD): stack entries that hold the deferred child
@@ -797,8 +813,8 @@ int render_accum_impl(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev,
   const auto launch_shade = rs ? ptd_rs::launch_shade : ptd::launch_shade;
   const auto launch_shadow = rs ? ptd_rs::launch_shadow : ptd::launch_shadow;
   const auto launch_paths_exact = rs ? ptd_rs::launch_paths : ptd::launch_paths;
-  const auto launch_paths = (ctx->fast_arith && !rs) ? ptd_fast::launch_paths : launch_paths_exact;  // the fast build has packed entries only
-  const int pipeline = no_alloc ? 0 : ctx->pipeline;
+  const auto launch_paths = merged ? ((ctx->fast_arith && !rs) ? ptd_fast::launch_paths_merged : (rs ? ptd_rs::launch_paths_merged : ptd::launch_paths_merged))
+                                   : ((ctx->fast_arith && !rs) ? ptd_fast::launch_paths : launch_paths_exact);  // the fast build has packed entries only
   // Concurrent bands (path pipeline): the frame is cut into `conc` bands of tiles, each with its own state, queues and stream,
   // and their launches are enqueued alternately. Every k_paths launch ends with a tail in which most of the GPU idles while the
   // last waves finish their vertices (a 1080p launch is only ~5 rounds of resident waves); the other band's launch fills it.
@@ -997,36 +1013,12 @@ int render_accum_impl(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev,
         for (uint32_t b = 0; b < kBatch; ++b, ++iter) {
           // the queue is rebuilt on the last iteration of a batch (every iteration in the split pipeline,
           // whose shadow queue is an append anyway) and re-used as it stands in between
-          const bool compact = split || ctx->sort_rays || ctx->compact_every <= 1 || (b + 1) % ctx->compact_every == 0 || b + 1 == kBatch;
-          if (ctx->sort_rays && iter > 0) {
-            // EXPERIMENT: k_extend walks the queue in (origin cell, octant) order; k_shade keeps the tile order
-            const uint32_t key_bits = 3u * ctx->sort_bits + 3u;
-            ptd::launch_ray_keys(st, st.queue[parity], PT_CNT_QUEUE0 + parity, bound, ctx->scene_lo, ctx->scene_hi, ctx->sort_bits,
-                                 ctx->sort_rays, ctx->sort_keys[0], st.ray_o, st.ray_d, stream);
-            if (ptd::sort_queue(ctx->sort_temp, ctx->sort_temp_bytes, ctx->sort_keys[0], ctx->sort_keys[1], st.queue[parity],
-                                ctx->sort_queue_out, bound, key_bits + 0u, stream) != 0)
-              return fail(ctx, PT_ERR_DEVICE, "radix sort failed");
-            pt_dev_state sorted = st;
-            sorted.queue[parity] = ctx->sort_queue_out;
-            timed(PT_K_EXTEND, [&] { launch_extend(sc, sorted, parity, bound, trace_block, ctx->trace_blocks, stream); });
-          } else {
-            timed(PT_K_EXTEND, [&] { launch_extend(sc, st, parity, bound, trace_block, ctx->trace_blocks, stream); });
-          }
+          const bool compact = split || ctx->compact_every <= 1 || (b + 1) % ctx->compact_every == 0 || b + 1 == kBatch;
+          timed(PT_K_EXTEND, [&] { launch_extend(sc, st, parity, bound, trace_block, ctx->trace_blocks, stream); });
           timed(PT_K_SHADE, [&] {
             launch_shade(sc, f, st, parity, bound, trace_block, ctx->shade_blocks, n_lights != 0, split, compact, stream);
           });
-          if (split && ctx->sort_rays && ctx->sort_shadow) {
-            // shadow queue by the shadow origin (pend[2]) and the first light sample's direction (req[0])
-            const uint32_t key_bits = 3u * ctx->sort_bits + 3u;
-            ptd::launch_ray_keys(st, st.queue_shadow, PT_CNT_SHADOW, bound, ctx->scene_lo, ctx->scene_hi, ctx->sort_bits, ctx->sort_rays,
-                                 ctx->sort_keys[0], st.pend + 2 * static_cast<size_t>(st.slot_stride), st.req, stream);
-            if (ptd::sort_queue(ctx->sort_temp, ctx->sort_temp_bytes, ctx->sort_keys[0], ctx->sort_keys[1], st.queue_shadow,
-                                ctx->sort_shadow_out, bound, key_bits, stream) != 0)
-              return fail(ctx, PT_ERR_DEVICE, "radix sort failed");
-            pt_dev_state sorted = st;
-            sorted.queue_shadow = ctx->sort_shadow_out;
-            timed(PT_K_SHADOW, [&] { launch_shadow(sc, f, sorted, bound, trace_block, ctx->trace_blocks, stream); });
-          } else if (split) timed(PT_K_SHADOW, [&] { launch_shadow(sc, f, st, bound, trace_block, ctx->trace_blocks, stream); });
+          if (split) timed(PT_K_SHADOW, [&] { launch_shadow(sc, f, st, bound, trace_block, ctx->trace_blocks, stream); });
           if (compact) parity ^= 1u;
         }
         PT_HIP(ctx, hipGetLastError());
@@ -1088,6 +1080,7 @@ int render_accum_impl(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev,
     stats_out->nan_samples = total(PT_ST_NANS);
     stats_out->iterations = iter;
     stats_out->scene_in_lds = sc.scene_in_lds;
+    stats_out->merged_walk = merged ? 1u : 0u;
     pt_kernel_stats* per[PT_K_COUNT + 1] = {nullptr, &stats_out->extend, &stats_out->shade, &stats_out->shadow, &stats_out->path_kernel};
     stats_out->path_kernel.launches = launches[PT_K_PATHS];
     for (int k = PT_K_EXTEND; k < PT_K_COUNT; ++k) {
@@ -1156,10 +1149,13 @@ extern "C" pt_ctx* pt_create_multi(const int* device_ids, int n) {
     fail(nullptr, PT_ERR_INVALID, "pt_create_multi: need 1..%d device ids", kMaxDevices);
     return nullptr;
   }
+  std::vector<int> ids(device_ids, device_ids + n);
+  for (int& id : ids)
+    if (id < 0) id = 0;  // pt_create's rule: a negative id picks GPU 0 — applied BEFORE the duplicate check, so {-1, 0} is refused
   for (int i = 0; i < n; ++i)
     for (int j = 0; j < i; ++j)
-      if (device_ids[i] == device_ids[j]) {
-        fail(nullptr, PT_ERR_INVALID, "pt_create_multi: device %d listed twice", device_ids[i]);
+      if (ids[i] == ids[j]) {
+        fail(nullptr, PT_ERR_INVALID, "pt_create_multi: device %d listed twice", ids[i]);
         return nullptr;
       }
   RcclApi& api = rccl();
@@ -1169,7 +1165,7 @@ extern "C" pt_ctx* pt_create_multi(const int* device_ids, int n) {
   }
   std::vector<pt_ctx*> members;
   for (int i = 0; i < n; ++i) {
-    pt_ctx* m = pt_create(device_ids[i] < 0 ? 0 : device_ids[i]);
+    pt_ctx* m = pt_create(ids[i]);
     if (!m) {
       for (pt_ctx* x : members) pt_destroy(x);
       return nullptr;  // pt_create left its message

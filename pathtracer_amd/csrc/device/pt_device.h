@@ -7,6 +7,10 @@
 
 #include "pathtracer_amd.h"
 
+// Rows of a lane's traversal stack beyond its LDS rows (private memory; traverse() in pt_kernels.hip). The host only chooses a short
+// LDS stack when the tree's depth fits LDS rows + these.
+#define PT_DEEP_LEVELS 48u
+
 // counters[] words
 enum { PT_CNT_QUEUE0 = 0, PT_CNT_QUEUE1 = 1, PT_CNT_QUEUE2 = 2, PT_CNT_SHADOW = 3, PT_CNT_WORDS = 4 };
 // stats[] words (unsigned long long), order of flush_tally()
@@ -96,12 +100,10 @@ void launch_shadow(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_s
 void launch_paths(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity, uint32_t cnt_in,
                   uint32_t cnt_out, uint32_t cnt_zero, uint32_t max_entries, uint32_t block, uint32_t max_blocks,
                   uint32_t max_vertices, uint32_t xcd_chunk, hipStream_t s);
-// experiment: ray re-ordering (pt_sort.hip)
-size_t sort_temp_bytes(uint32_t n);
-void launch_ray_keys(const pt_dev_state& st, const uint32_t* queue, uint32_t counter_word, uint32_t bound, const float* lo, const float* hi,
-                     uint32_t bits, uint32_t mode, uint32_t* keys, const float4* origin, const float4* dir, hipStream_t s);
-int sort_queue(void* temp, size_t temp_bytes, uint32_t* keys_in, uint32_t* keys_out, const uint32_t* q_in, uint32_t* q_out, uint32_t n,
-               uint32_t key_bits, hipStream_t s);
+void launch_paths_merged(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity, uint32_t cnt_in,
+                         uint32_t cnt_out, uint32_t cnt_zero, uint32_t max_entries, uint32_t block, uint32_t max_blocks,
+                         uint32_t max_vertices, uint32_t xcd_chunk, hipStream_t s);
+size_t merged_lds_bytes(const pt_dev_scene& sc, uint32_t block);
 void launch_sum_stats(const pt_dev_state& st, hipStream_t s);
 void launch_finalize(const pt_dev_frame& f, const pt_dev_state& st, float4* accum_out, uint32_t* primary_out, hipStream_t s);
 void launch_resolve(const float4* accum, uint32_t pixel_count, uint32_t* rgba8, hipStream_t s);
@@ -118,10 +120,18 @@ void launch_shadow(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_s
 void launch_paths(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity, uint32_t cnt_in,
                   uint32_t cnt_out, uint32_t cnt_zero, uint32_t max_entries, uint32_t block, uint32_t max_blocks,
                   uint32_t max_vertices, uint32_t xcd_chunk, hipStream_t s);
+void launch_paths_merged(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity, uint32_t cnt_in,
+                         uint32_t cnt_out, uint32_t cnt_zero, uint32_t max_entries, uint32_t block, uint32_t max_blocks,
+                         uint32_t max_vertices, uint32_t xcd_chunk, hipStream_t s);
+size_t merged_lds_bytes(const pt_dev_scene& sc, uint32_t block);
 }  // namespace ptd_rs
 
 namespace ptd_fast {  // pt_kernels_fast.hip: k_paths with the shading half on hardware-approximate arithmetic (PT_ARITH=fast)
 void launch_paths(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity, uint32_t cnt_in,
                   uint32_t cnt_out, uint32_t cnt_zero, uint32_t max_entries, uint32_t block, uint32_t max_blocks,
                   uint32_t max_vertices, uint32_t xcd_chunk, hipStream_t s);
+void launch_paths_merged(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity, uint32_t cnt_in,
+                         uint32_t cnt_out, uint32_t cnt_zero, uint32_t max_entries, uint32_t block, uint32_t max_blocks,
+                         uint32_t max_vertices, uint32_t xcd_chunk, hipStream_t s);
+size_t merged_lds_bytes(const pt_dev_scene& sc, uint32_t block);
 }  // namespace ptd_fast

@@ -178,6 +178,7 @@ __device__ __forceinline__ void flush_tally(const Tally& t, const pt_dev_state& 
 struct Hit {
   float t, u, v;
   uint32_t tri;
+  uint32_t opq = 0;  // the accepted triangle's tag word, tri_pos[3 tri].w: non-zero = its material is provably opaque (read by shadow walks only)
 };
 
 // ray_aabb_intersect, main.comp:169-185, for BOTH children of a pair at once. inv_dir is
@@ -192,7 +193,7 @@ struct Hit {
 typedef float f2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void ray_box_pair(vec3 o, vec3 inv, const float4& q0, const float4& q1, const float4& q2, float t_best,
-                                             bool& hit_l, bool& hit_r, float& dist_l, float& dist_r) {
+                                             bool& hit_l, bool& hit_r, float& dist_l, float& dist_r, float& exit_l, float& exit_r) {
 #pragma clang fp contract(off)
   // q0 = {lmin.x, rmin.x, lmin.y, rmin.y}, q1 = {lmin.z, rmin.z, lmax.x, rmax.x}, q2 = {lmax.y, rmax.y, lmax.z, rmax.z}:
   // every {left, right} operand pair of the packed instructions is an aligned register pair as loaded
@@ -207,6 +208,8 @@ __device__ __forceinline__ void ray_box_pair(vec3 o, vec3 inv, const float4& q0,
   const float far_r = gmin(gmin(gmax(ax.y, bx.y), gmax(ay.y, by.y)), gmax(az.y, bz.y));
   dist_l = near_l;
   dist_r = near_r;
+  exit_l = far_l;
+  exit_r = far_r;
   hit_l = near_l <= far_l && !(far_l < 0.0f) && near_l < t_best;  // :179, behind-origin cull, :284
   hit_r = near_r <= far_r && !(far_r < 0.0f) && near_r < t_best;
 }
@@ -235,7 +238,7 @@ struct Tracer {
 
 // Rows of the traversal stack beyond a lane's LDS rows (scenes in global memory may run with a short LDS stack so that
 // more waves fit a CU): a private array, i.e. scratch memory, touched only by the rare ray whose stack outgrows the LDS rows.
-constexpr uint32_t kDeepLevels = 48;
+constexpr uint32_t kDeepLevels = PT_DEEP_LEVELS;  // pt_device.h: the host sizes the short LDS stack against it
 
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 __device__ __forceinline__ void stack_store(uint32_t addr, uint32_t v) { *reinterpret_cast<lds_u32*>(static_cast<uintptr_t>(addr)) = v; }
@@ -340,7 +343,9 @@ __device__ __forceinline__ uint2 fetch_child(const float4* pairs, uint32_t rec, 
 }
 
 // ray_triangle_intersect, main.comp:189-217
-template <bool IN_LDS>
+// TAG: also note the accepted triangle's tag word (shadow walks of scenes that are not all-opaque; a template flag rather than
+// dead-code elimination's business: the unconditional form moved cfg2's register allocation, -2 %)
+template <bool IN_LDS, bool TAG = false>
 __device__ __forceinline__ void ray_triangle(const Tracer& tr, vec3 o, vec3 d, uint32_t tri, Hit& h) {
 #pragma clang fp contract(off)
   float4 v0, v1, v2;
@@ -367,6 +372,7 @@ __device__ __forceinline__ void ray_triangle(const Tracer& tr, vec3 o, vec3 d, u
     h.u = u;
     h.v = v;
     h.tri = tri;
+    if (TAG) h.opq = fbits(v0.w);
   }
 }
 
@@ -387,7 +393,22 @@ __device__ __forceinline__ void ray_triangle(const Tracer& tr, vec3 o, vec3 d, u
 //  - scenes read from global memory (latency bound) keep inner and leaf handling as the two
 //    arms of one trip, so every lane issues its next fetch every trip (while-while was
 //    13 % slower on the 1 M-triangle soup: lanes parked on a leaf have no load in flight).
-template <bool IN_LDS, bool ANY_HIT>
+//
+// Which of two hit children is entered first. Closest-hit walks owe the reference its order (nearer first, the right one on a
+// tie: Q14 — the tie-breaks between equally distant triangles depend on it). The answer of an ANY-HIT walk does not depend on the
+// order, only its length does: it enters the child in whose box the ray stays longer, counted from the origin on
+// (t_far - max(t_near, 0)), the left one on a tie — on the 5 M-triangle rocks -8.6 % of ALL node visits against nearer-first,
+// -10.7 % on the 1 M-triangle soup (scripts/anyhit_order_model.py tried ten orders on the oracle, whose ORC_FLAG_ANYHIT_SPAN_ORDER
+// mirrors this one so that the work counters still compare equal). Scenes read from global memory only: the few any-hit walks of an
+// LDS-resident scene are short, and the extra registers cost cfg2 3 % (measured).
+template <bool ANY_HIT>
+__device__ __forceinline__ bool left_first(float dist_l, float dist_r, float exit_l, float exit_r) {
+#pragma clang fp contract(off)
+  if (ANY_HIT) return (exit_l - gmax(dist_l, 0.0f)) >= (exit_r - gmax(dist_r, 0.0f));
+  return dist_l < dist_r;
+}
+
+template <bool IN_LDS, bool ANY_HIT, bool TAG = false>
 __device__ __forceinline__ void traverse(const Tracer& tr, vec3 o, vec3 d, Hit& h, Tally& tally) {
   ++tally.rays;
   const vec3 inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
@@ -416,11 +437,11 @@ __device__ __forceinline__ void traverse(const Tracer& tr, vec3 o, vec3 d, Hit& 
     ++tally.visits;
     const float4 q0 = fetch16<IN_LDS>(tr.pairs, 4 * ref), q1 = fetch16<IN_LDS>(tr.pairs, 4 * ref + 1);
     const float4 q2 = fetch16<IN_LDS>(tr.pairs, 4 * ref + 2), q3 = fetch16<IN_LDS>(tr.pairs, 4 * ref + 3);
-    float dist_l, dist_r;
+    float dist_l, dist_r, exit_l, exit_r;
     bool hit_l, hit_r;
-    ray_box_pair(o, inv, q0, q1, q2, h.t, hit_l, hit_r, dist_l, dist_r);
+    ray_box_pair(o, inv, q0, q1, q2, h.t, hit_l, hit_r, dist_l, dist_r, exit_l, exit_r);
     if (hit_l || hit_r) {
-      const bool go_left = hit_l && (!hit_r || dist_l < dist_r);  // equal distances: right is near (Q14)
+      const bool go_left = hit_l && (!hit_r || left_first<false>(dist_l, dist_r, exit_l, exit_r));  // equal distances: right is near (Q14); LDS scenes: any-hit walks too
       if (hit_l && hit_r) {
         // the far side: the child itself for LDS scenes (a pop then needs no fetch: +0.4 % on cfg2), else (record, side)
         if (IN_LDS) stack_store(sp, go_left ? (fbits(q3.z) << 16) | fbits(q3.w) : (fbits(q3.x) << 16) | fbits(q3.y));
@@ -437,12 +458,12 @@ __device__ __forceinline__ void traverse(const Tracer& tr, vec3 o, vec3 d, Hit& 
     if (ANY_HIT) {
       for (uint32_t i = 0; i < cnt; ++i) {
         ++tally.tests;
-        ray_triangle<IN_LDS>(tr, o, d, ref + i, h);
+        ray_triangle<IN_LDS, TAG>(tr, o, d, ref + i, h);
         if (h.tri != kNoHit) return true;
       }
     } else {
       tally.tests += cnt;
-      for (uint32_t i = 0; i < cnt; ++i) ray_triangle<IN_LDS>(tr, o, d, ref + i, h);
+      for (uint32_t i = 0; i < cnt; ++i) ray_triangle<IN_LDS, TAG>(tr, o, d, ref + i, h);
     }
     pop();
     return false;
@@ -471,22 +492,22 @@ __device__ __forceinline__ void traverse(const Tracer& tr, vec3 o, vec3 d, Hit& 
         if (ANY_HIT) {
           for (uint32_t i = 0; i < cnt; ++i) {
             ++tally.tests;
-            ray_triangle<IN_LDS>(tr, o, d, ref + i, h);
+            ray_triangle<IN_LDS, TAG>(tr, o, d, ref + i, h);
             if (h.tri != kNoHit) return;
           }
         } else {
           tally.tests += cnt;
-          for (uint32_t i = 0; i < cnt; ++i) ray_triangle<IN_LDS>(tr, o, d, ref + i, h);
+          for (uint32_t i = 0; i < cnt; ++i) ray_triangle<IN_LDS, TAG>(tr, o, d, ref + i, h);
         }
       } else {
         ++tally.visits;
         const float4 q0 = fetch16<IN_LDS>(tr.pairs, 4 * ref), q1 = fetch16<IN_LDS>(tr.pairs, 4 * ref + 1);
         const float4 q2 = fetch16<IN_LDS>(tr.pairs, 4 * ref + 2), q3 = fetch16<IN_LDS>(tr.pairs, 4 * ref + 3);
-        float dist_l, dist_r;
+        float dist_l, dist_r, exit_l, exit_r;
         bool hit_l, hit_r;
-        ray_box_pair(o, inv, q0, q1, q2, h.t, hit_l, hit_r, dist_l, dist_r);
+        ray_box_pair(o, inv, q0, q1, q2, h.t, hit_l, hit_r, dist_l, dist_r, exit_l, exit_r);
         if (hit_l || hit_r) {
-          const bool go_left = hit_l && (!hit_r || dist_l < dist_r);
+          const bool go_left = hit_l && (!hit_r || left_first<ANY_HIT>(dist_l, dist_r, exit_l, exit_r));
           if (hit_l && hit_r) {
 #if PT_STACK_CHILD  // the far side: the child itself, or (record, side)
             const uint32_t e = ((go_left ? fbits(q3.z) : fbits(q3.x)) << 7) | (go_left ? fbits(q3.w) : fbits(q3.y));
@@ -697,12 +718,13 @@ __device__ __forceinline__ float4 sample_texture(const pt_dev_scene& sc, int ind
   const int y0 = wrap_coord(j0, H, wrap_t), y1 = wrap_coord(j0 + 1, H, wrap_t);
   const float4 t00 = texel(sc.texels, rec.x, W, x0, y0), t10 = texel(sc.texels, rec.x, W, x1, y0);
   const float4 t01 = texel(sc.texels, rec.x, W, x0, y1), t11 = texel(sc.texels, rec.x, W, x1, y1);
-  const float w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
+  // lerp(b, lerp(a, t00, t10), lerp(a, t01, t11)) with lerp(w, x, y) = x + w * (y - x): constant for four equal texels, as every
+  // hardware filter and llvmpipe are — an all-opaque texture's alpha is exactly 1.0 (same text as the oracle's sample_texture)
   float4 r;
-  r.x = ((w00 * t00.x + w10 * t10.x) + w01 * t01.x) + w11 * t11.x;
-  r.y = ((w00 * t00.y + w10 * t10.y) + w01 * t01.y) + w11 * t11.y;
-  r.z = ((w00 * t00.z + w10 * t10.z) + w01 * t01.z) + w11 * t11.z;
-  r.w = ((w00 * t00.w + w10 * t10.w) + w01 * t01.w) + w11 * t11.w;
+  { const float lo = t00.x + a * (t10.x - t00.x), hi = t01.x + a * (t11.x - t01.x); r.x = lo + b * (hi - lo); }
+  { const float lo = t00.y + a * (t10.y - t00.y), hi = t01.y + a * (t11.y - t01.y); r.y = lo + b * (hi - lo); }
+  { const float lo = t00.z + a * (t10.z - t00.z), hi = t01.z + a * (t11.z - t01.z); r.z = lo + b * (hi - lo); }
+  { const float lo = t00.w + a * (t10.w - t00.w), hi = t01.w + a * (t11.w - t01.w); r.w = lo + b * (hi - lo); }
   return r;
 }
 
@@ -918,7 +940,8 @@ __global__ __launch_bounds__(256) void k_extend(pt_dev_scene sc, pt_dev_state st
 
 // ray_scene_intersect_with_transparency, main.comp:306-332. Returns the transparency and
 // leaves the last traversal's result in h.
-template <bool IN_LDS, bool ALL_OPAQUE, bool TEXTURED = true>
+// RESUME (the merged walk of k_paths_merged): the first step's traversal has been done by the caller and h holds its hit.
+template <bool IN_LDS, bool ALL_OPAQUE, bool TEXTURED = true, bool RESUME = false>
 __device__ __forceinline__ float shadow_walk(const pt_dev_scene& sc, const ShadeData& sd, const Tracer& tr, vec3 origin, vec3 dir,
                                              Hit& h, Tally& tally) {
   float transparency = 1.0f;
@@ -929,10 +952,16 @@ __device__ __forceinline__ float shadow_walk(const pt_dev_scene& sc, const Shade
     return h.tri == kNoHit ? 1.0f : 0.0f;
   }
   for (uint32_t step = 0; step < kMaxTransparencySteps; ++step) {
-    h.t = kInfinity;
-    h.tri = kNoHit;
-    traverse<IN_LDS, false>(tr, origin, dir, h, tally);
+    if (!(RESUME && step == 0)) {
+      h.t = kInfinity;
+      h.tri = kNoHit;
+      traverse<IN_LDS, false, true>(tr, origin, dir, h, tally);
+    }
     if (h.tri == kNoHit) break;
+    // The closest hit lies on a triangle whose material is provably opaque (tagged at upload: base_color_factor.a == 1 and no
+    // base-colour texture or one whose alpha bytes are all 255): alpha == 1.0 whatever the uv, so the walk returns 0 (main.comp:325)
+    // without the 112-byte attribute fetch, the material and the texture tap (the oracle's ORC_FLAG_OPAQUE_TRIANGLES mirrors it).
+    if (h.opq != 0u) return 0.0f;
     const vec3 wuv = mk(1.0f - h.u - h.v, h.u, h.v);
     vec3 pos;
     float tu, tv;
@@ -962,6 +991,42 @@ struct PathRegs {
   uint32_t rng, light_steps, transp_steps, sample;
 };
 
+// ---- k_paths_merged: a vertex's light samples wait for the NEXT traversal phase (DEFER) ----------------------------------------
+// The lanes of a wave walk in lock step per phase, and a phase lasts as long as its longest lane: closest hit of vertex k, then the
+// shadow walk(s) of vertex k. Merged, a lane that has finished its shadow walk goes straight on with its next ray, and the wave pays
+// max over lanes of (shadow + closest) instead of max(shadow) + max(closest): scripts/merge_model.py replays k_paths' schedule on the
+// oracle's trip log: -21 % wave trips on the 5 M-triangle rocks, -23 % on the atrium, -18 % on the 1 M-triangle soup.
+// So shade_vertex<DEFER> walks nothing: every light sample it could not decide with a one-triangle test is left in `Pending` (its
+// direction in registers, the factors of its contribution in the lane's LDS stash: the SPLIT pipeline's request, kept on chip) and the
+// vertex's `color +=` (main.comp:545 / :552) is done by resolve_pending after the next merged walk. Same expressions in the same
+// order as the fused form (the SPLIT form has been parity-tested since round 1), so the bits do not change.
+enum : uint32_t {
+  PEND_S0 = 1u, PEND_S1 = 2u,        // slot j holds a light sample that needs a walk
+  PEND_AREA0 = 4u, PEND_AREA1 = 8u,  // slot j is the area sample (its contribution replaces area_light; others add to punctual)
+  PEND_TAP0 = 16u, PEND_TAP1 = 32u,  // slot j's emitter has an emissive texture: the reference taps it only if the sample is visible
+  PEND_SHADED = 64u,                 // a colour update is due
+  PEND_ENDED = 128u                  // the path ended at that vertex: finish the sample after the update
+};
+struct Pending {
+  vec3 origin;        // the vertex's shadow origin (pos + NORMAL_DELTA * n)
+  vec3 l0, l1;        // directions of the (at most two) light samples
+  vec3 emission, m;   // color += ((emission + punctual + area_light) * af) * m
+  float af;
+  uint32_t flags = 0;
+};
+struct Stash {        // LDS byte addresses of this lane's stash: per slot two quads {a_factor.xyz, correction | brdf.xyz, n_dot_l} and a pair {pdf, limit}
+  uint32_t quad, quad_stride, pair, pair_stride;
+};
+typedef float pt_f2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) pt_f4 lds_pt_f4;
+typedef __attribute__((address_space(3))) pt_f2 lds_pt_f2;
+__device__ __forceinline__ void lds_store16(uint32_t addr, float a, float b, float c, float d) {
+  *reinterpret_cast<lds_pt_f4*>(static_cast<uintptr_t>(addr)) = pt_f4{a, b, c, d};
+}
+__device__ __forceinline__ pt_f4 lds_load16(uint32_t addr) { return *reinterpret_cast<lds_pt_f4*>(static_cast<uintptr_t>(addr)); }
+__device__ __forceinline__ void lds_store8(uint32_t addr, float a, float b) { *reinterpret_cast<lds_pt_f2*>(static_cast<uintptr_t>(addr)) = pt_f2{a, b}; }
+__device__ __forceinline__ pt_f2 lds_load8(uint32_t addr) { return *reinterpret_cast<lds_pt_f2*>(static_cast<uintptr_t>(addr)); }
+
 // SPLIT (scenes read from global memory with at least one light): the shadow walks do NOT run
 // here. Every light sample is written as a request (direction, the factors of its
 // contribution, the distance test's operands) and the vertex's `color +=` is deferred to
@@ -969,11 +1034,14 @@ struct PathRegs {
 // ran 2x slower per ray inside the 128..168-register shading kernel). `shaded` tells the
 // caller to queue the slot for k_shadow. The deferred arithmetic is the same expressions in
 // the same order, so results stay bit-identical to the fused form.
-template <bool IN_LDS, bool ALL_OPAQUE, bool SPLIT, bool PUNCTUAL = true, bool TEXTURED = true>
+// DEFER (k_paths_merged, at most two light samples per vertex): like SPLIT, but the requests stay on chip (`pend`, `stash`), the
+// one-triangle shortcuts of all-opaque scenes are taken here, and a finished path keeps its colour and throughput in `p` until
+// resolve_pending has added the vertex's direct light (it then ends the sample and resets them).
+template <bool IN_LDS, bool ALL_OPAQUE, bool SPLIT, bool PUNCTUAL = true, bool TEXTURED = true, bool DEFER = false>
 __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const ShadeData& sd, const pt_dev_frame& f, const pt_dev_state& st,
                                              const Tracer& tr, uint32_t n_lights, vec3 bg_linear, uint32_t slot,
                                              const Hit& hit, vec3 ray_dir, PathRegs& p, vec3& next_o, vec3& next_d,
-                                             Tally& tally, Tally& walks, bool& shaded) {
+                                             Tally& tally, Tally& walks, bool& shaded, Pending* pend = nullptr, const Stash* stash = nullptr) {
   vec3 indirect = p.indirect, color = p.color;
   uint32_t rng = p.rng, light_steps = p.light_steps, transp_steps = p.transp_steps, sample = p.sample;
   bool alive = false;
@@ -1030,7 +1098,11 @@ __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const Shade
       vec3 ewuv = splat(0.0f);
       float4 q0 = l0, q1 = l0, q2 = l0;
       // PUNCTUAL = false: the scene has no directional or point light, every sample is the area sample
-      const uint32_t kind = !PUNCTUAL ? 2u : (j < n_dir ? 0u : (j < n_punctual ? 1u : 2u));
+      uint32_t kind = !PUNCTUAL ? 2u : (j < n_dir ? 0u : (j < n_punctual ? 1u : 2u));
+      // (DEFER: the kind is wave-uniform; pinned to a scalar register so that every test of it below is a scalar compare. Left alone,
+      // hipcc formed `j < n_punctual` as a LANE MASK (v_cndmask + v_cmp under the trip's exec mask) and re-tested that mask further
+      // down the trip — the instruction pair scripts/check_isa.py exists to keep out of the kernels)
+      if (DEFER && PUNCTUAL) kind = __builtin_amdgcn_readfirstlane(kind);
       if (kind == 0u) {
         l0 = fetch16<IN_LDS>(sd.dlights, 2 * j);
         l = -xyz(fetch16<IN_LDS>(sd.dlights, 2 * j + 1));
@@ -1064,7 +1136,23 @@ __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const Shade
         l = normalize(l);
       }
 
-      if (SPLIT) {
+      if (DEFER && ALL_OPAQUE) {  // the one-triangle shortcuts (below, in the fused form's words): a sample they decide is occluded and adds nothing
+        Hit sh{kInfinity, 0.0f, 0.0f, kNoHit};
+        if (kind == 2u) {
+          ++walks.tests;
+          ray_triangle<IN_LDS>(tr, shadow_origin, l, etri, sh);
+        }
+        if (sh.tri == kNoHit && !(kind == 2u && etri == hit.tri)) {
+          ++walks.tests;
+          ray_triangle<IN_LDS>(tr, shadow_origin, l, hit.tri, sh);
+        }
+        if (sh.tri != kNoHit) {
+          ++walks.rays;
+          ++walks.paths;
+          continue;
+        }
+      }
+      if (SPLIT || DEFER) {
         vec3 a_factor;       // the radiance / emission factor that transparency multiplies
         float n_dot_l, pdf = 1.0f, limit = -kInfinity * 2.0f, correction = 0.0f;  // -inf: `x < limit` never holds (no distance test for directional lights)
         uint32_t tap_if_visible = 0;
@@ -1097,6 +1185,15 @@ __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const Shade
           }
         }
         const vec3 brdf = microfacet_brdf(nrm, view, l, metal, a2, base_color);
+        if (DEFER) {  // slot j (the host sends scenes with more than two light samples per vertex to k_paths)
+          if (j == 0u) pend->l0 = l;
+          else pend->l1 = l;
+          pend->flags |= (PEND_S0 << j) | (kind == 2u ? PEND_AREA0 << j : 0u) | (tap_if_visible ? PEND_TAP0 << j : 0u);
+          lds_store16(stash->quad + 2u * j * stash->quad_stride, a_factor.x, a_factor.y, a_factor.z, correction);
+          lds_store16(stash->quad + (2u * j + 1u) * stash->quad_stride, brdf.x, brdf.y, brdf.z, n_dot_l);
+          lds_store8(stash->pair + j * stash->pair_stride, pdf, limit);
+          continue;
+        }
         float4* r = st.req + (static_cast<size_t>(j) * 4u) * st.slot_stride + slot;
         r[0] = make_float4(l.x, l.y, l.z, limit);
         r[st.slot_stride] = make_float4(a_factor.x, a_factor.y, a_factor.z, correction);
@@ -1116,6 +1213,19 @@ __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const Shade
         if (sh.tri != kNoHit) {
           ++walks.rays;
           ++walks.paths;  // in the shadow slice this word counts the rays decided by the shortcut (pt_stats.rays_shadow_shortcut)
+          continue;
+        }
+      }
+      if (ALL_OPAQUE && !IN_LDS && !(kind == 2u && etri == hit.tri)) {
+        // ... and so does the triangle the shading point lies on: a light on the far side of the surface sends the ray, which
+        // starts NORMAL_DELTA above that triangle, straight back through it, and the walk would need a full descent of the tree
+        // to find that out (the 5 M-triangle rocks: 51 % of the shadow rays, -12.8 % node visits; ORC_FLAG_SELF_FIRST mirrors it).
+        // Scenes read from global memory only (an LDS-resident scene's walk is a handful of ds_reads; cfg2 lost 3 % to the extra code).
+        ++walks.tests;
+        ray_triangle<IN_LDS>(tr, shadow_origin, l, hit.tri, sh);
+        if (sh.tri != kNoHit) {
+          ++walks.rays;
+          ++walks.paths;
           continue;
         }
       }
@@ -1163,18 +1273,27 @@ __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const Shade
       deferred_emission = emission;
       deferred_origin = shadow_origin;
     }
+    if (DEFER) {
+      shaded = true;
+      pend->origin = shadow_origin;
+      pend->emission = emission;
+      pend->m = indirect;
+      pend->af = 1.0f;
+      pend->flags |= PEND_SHADED;
+    }
 
     // (a provably all-opaque scene has alpha == 1.0f at every vertex: the pass-through arm is dead)
     if (!ALL_OPAQUE && alpha < 1.0f && transp_steps < kMaxTransparencySteps) {  // main.comp:542-547
       ++transp_steps;
       if (SPLIT) alpha_factor = alpha;
+      else if (DEFER) pend->af = alpha;
       else color = color + direct * alpha * indirect;
       indirect = indirect * (1.0f - alpha);
       next_o = pos + kNormalDelta * ray_dir;
       next_d = ray_dir;
     } else {  // main.comp:549-577
       ++light_steps;
-      if (!SPLIT) color = color + direct * indirect;
+      if (!SPLIT && !DEFER) color = color + direct * indirect;
       const Basis basis = orthogonal_matrix(nrm);  // shared by both samplers (:383, :399)
       float diffuse_pdf, microfacet_pdf;
       const vec3 diffuse_dir = diffuse_sample(nrm, basis, rng, diffuse_pdf);
@@ -1208,7 +1327,8 @@ __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const Shade
   }
 
   if (path_done) {  // end of trace() + next stratum of this pixel, or retire the slot (main():597-612)
-    if (!(SPLIT && shaded)) {
+    if (DEFER && shaded) pend->flags |= PEND_ENDED;  // resolve_pending ends the sample once the vertex's direct light is in
+    if (!((SPLIT || DEFER) && shaded)) {
       float4 acc = st.accum[slot];
       finish_sample(color, indirect, bg_linear, acc, tally);
       st.accum[slot] = acc;
@@ -1221,8 +1341,10 @@ __device__ __forceinline__ bool shade_vertex(const pt_dev_scene& sc, const Shade
       ++tally.paths;
       alive = true;
     }
-    indirect = splat(1.0f);
-    color = splat(0.0f);
+    if (!(DEFER && shaded)) {  // (DEFER: the finished path's colour and throughput stay in p until resolve_pending has used them)
+      indirect = splat(1.0f);
+      color = splat(0.0f);
+    }
     light_steps = 0;
     transp_steps = 0;
   } else {
@@ -1358,6 +1480,7 @@ __global__ __launch_bounds__(256, ALL_OPAQUE ? PT_SHADOW_MIN_WAVES_OPAQUE : PT_S
       const float4* h = st.pend + slot;
       const float4 h0 = h[0], h1 = h[ss], h2 = h[2 * ss], h3 = h[3 * ss];
       const vec3 origin = xyz(h2);
+      const uint32_t self_tri = ALL_OPAQUE ? st.hit[slot].x : kNoHit;  // the triangle the vertex lies on (k_extend's result, untouched until the next iteration)
       vec3 punctual = splat(0.0f), area_light = splat(0.0f);
       for (uint32_t j = 0; j < n_lights; ++j) {
         const float4* r = st.req + (static_cast<size_t>(j) * 4u) * ss + slot;
@@ -1371,6 +1494,15 @@ __global__ __launch_bounds__(256, ALL_OPAQUE ? PT_SHADOW_MIN_WAVES_OPAQUE : PT_S
           if (sh.tri != kNoHit) {
             ++walks.rays;
             ++walks.paths;  // shortcut count (see shade_vertex)
+            continue;
+          }
+        }
+        if (ALL_OPAQUE && !(is_area && fbits(r3.y) == self_tri)) {  // the own-triangle-first shortcut of the fused form
+          ++walks.tests;
+          ray_triangle<false>(tr, origin, l, self_tri, sh);
+          if (sh.tri != kNoHit) {
+            ++walks.rays;
+            ++walks.paths;
             continue;
           }
         }
@@ -1404,6 +1536,256 @@ __global__ __launch_bounds__(256, ALL_OPAQUE ? PT_SHADOW_MIN_WAVES_OPAQUE : PT_S
 
 }  // namespace PT_KNS
 #endif  // !PT_FAST_ARITH
+
+// ---------------------------------------------------------------- the merged walk (k_paths_merged)
+// A lane's traversal jobs of one phase, walked one after the other in ONE loop: the pending light samples of the vertex it shaded
+// last (slots 0 and 1), then the closest hit of its next ray. All-opaque scenes: the shadow jobs are any-hit walks (first accepted
+// triangle decides; children entered longer-span-first), the closest-hit job keeps the reference's order (Q14). Other scenes: every
+// job is a closest-hit walk, and a shadow job is the FIRST step of ray_scene_intersect_with_transparency (main.comp:306-332): a miss
+// lets the sample through, a provably opaque hit (tri_pos tag) blocks it, and only a hit on a surface that may be transparent goes on
+// with the reference's step-by-step walk (shadow_walk<RESUME>, lanes in lock step: rare — cloth, glass).
+// A lane that finishes a job parks. Parked lanes are served together — results booked, next job started (three IEEE divides for
+// 1 / d) — once kMergedPark of them wait or nobody is walking: serving each lane the moment it parks would run that block up to 192
+// times per wave and phase for a lane or two at a time. Measured (same box, 1080p, rocks 64 spp / atrium 36 spp, Mrays/s; k_paths
+// 1511 / 1878): park 1: 1598 / 1857, 2: 1569 / 1874, 6: 1555 / 1924, 8: 1549 / 1933, 12: 1530 / 1928, 24: 1455 / 1861 (11 LDS rows).
+#ifndef PT_MERGED_PARK
+#define PT_MERGED_PARK 8
+#endif
+// Waves per SIMD the register allocator leaves room for in k_paths_merged: 5 (96 registers), as k_paths on these scenes. The first
+// version ran 3 x slower there: the four quads of a pair record, read as one 64-byte vector, lived in ONE 16-register tuple that was
+// spilled and reloaded whole on every inner-node trip to keep its last quad across the slab test (read in the ISA,
+// scripts/isa_fn.py); fetched as four pinned 128-bit values (fetch16x4) the loop holds 0-3 one-word spills. At 4 waves (128
+// registers, no spill at all) it only equals k_paths at 5.
+#ifndef PT_MERGED_MIN_WAVES
+#define PT_MERGED_MIN_WAVES 5
+#endif
+// 1: path state, deferred update and job rays parked in private memory around the walk and read back from there (tried against the
+// spills above before their cause was found; scratch latency at every job start costs more than the registers: -8 % / -17 %)
+#ifndef PT_MERGED_COLD
+#define PT_MERGED_COLD 0
+#endif
+constexpr uint32_t kMergedPark = PT_MERGED_PARK;
+
+//
+// `cold` is a private (scratch) array: it holds the first hit of a light sample that may be transparent until the walk is over
+// (COLD_HIT), and with PT_MERGED_COLD the path state, the deferred colour update and the jobs' rays around the walk. Its words:
+enum : uint32_t {
+  COLD_INDIRECT = 0, COLD_COLOR = 3, COLD_RNG = 6, COLD_CTR = 7, COLD_EMISSION = 8, COLD_M = 11, COLD_AF = 14,
+  COLD_ORIGIN = 15, COLD_L0 = 18, COLD_L1 = 21, COLD_RAY_O = 24, COLD_RAY_D = 27, COLD_HIT = 30 /* 2 x {t, u, v, tri} */, COLD_WORDS = 38
+};
+__device__ __forceinline__ void cold_put(volatile float* cold, uint32_t at, vec3 v) {
+  cold[at] = v.x;
+  cold[at + 1] = v.y;
+  cold[at + 2] = v.z;
+}
+__device__ __forceinline__ vec3 cold_get(volatile float* cold, uint32_t at) {
+  const float x = cold[at], y = cold[at + 1], z = cold[at + 2];
+  return mk(x, y, z);
+}
+
+template <bool ALL_OPAQUE, bool TEXTURED>
+__device__ __forceinline__ void merged_walk(const pt_dev_scene& sc, const ShadeData& sd, const Tracer& tr, const Stash& stash,
+                                            const Pending& pend, bool has_ray, vec3 ray_o, vec3 ray_d, volatile float* cold, Hit& h,
+                                            float& vis0, float& vis1, Tally& ext, Tally& walks, Tally& tally) {
+  uint32_t todo = (pend.flags & (PEND_S0 | PEND_S1)) | (has_ray ? 4u : 0u);  // bit 0 / 1: light sample 0 / 1, bit 2: the next ray (always last: h is its hit)
+  uint32_t cur = 0;                                                          // the job being walked (one bit), 0: none
+  vec3 o = splat(0.0f), d = splat(0.0f), inv = splat(0.0f);
+  uint32_t sp = tr.stack, ref = 0, cnt = 0, nd = 0;
+  bool live = false;
+  uint32_t deep[kDeepLevels];  // rows beyond the lane's LDS rows (private memory), as in traverse()
+  auto start = [&]() {         // the lane's next job (lowest bit of todo)
+    cur = todo & (0u - todo);
+    todo ^= cur;
+#if PT_MERGED_COLD
+    o = cold_get(cold, cur == 4u ? COLD_RAY_O : COLD_ORIGIN);
+    d = cold_get(cold, cur == 1u ? COLD_L0 : (cur == 2u ? COLD_L1 : COLD_RAY_D));
+#else
+    o = cur == 4u ? ray_o : pend.origin;
+    d = cur == 1u ? pend.l0 : (cur == 2u ? pend.l1 : ray_d);
+#endif
+    inv = mk(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    h.t = kInfinity;
+    h.tri = kNoHit;
+    sp = tr.stack;
+    nd = 0;
+    ref = tr.root_ref;  // root: never box-tested (Q13)
+    cnt = tr.root_cnt;
+    live = true;
+    if (cur == 4u) ++ext.rays;
+    else ++walks.rays;
+  };
+  if (todo) start();
+  for (;;) {
+    if (live) {  // one trip of the lane's walk: the two arms of traverse()'s global-memory loop
+      const bool any_hit = ALL_OPAQUE && cur != 4u;
+      bool need_pop = true;
+#ifdef PT_GUARD
+      if ((cnt > 0 ? (ref + cnt > tr.g_tris) : (ref >= tr.g_pairs)) || nd > kDeepLevels || sp < tr.stack || sp > tr.stack_end) {
+        printf("[guard] merged walk: ref %u cnt %u nd %u sp %u job %u (block %u thread %u)\n", ref, cnt, nd, sp, cur, blockIdx.x, threadIdx.x);
+        live = false;
+        need_pop = false;
+        h.tri = kNoHit;
+      } else
+#endif
+      if (cnt > 0) {
+        if (ALL_OPAQUE) {
+          for (uint32_t i = 0; i < cnt; ++i) {
+            ++ext.tests;
+            ray_triangle<false>(tr, o, d, ref + i, h);
+            if (any_hit && h.tri != kNoHit) {  // a shadow job of an all-opaque scene: decided
+              live = false;
+              need_pop = false;
+              break;
+            }
+          }
+        } else {
+          ext.tests += cnt;
+          for (uint32_t i = 0; i < cnt; ++i) ray_triangle<false, true>(tr, o, d, ref + i, h);
+        }
+      } else {
+        ++ext.visits;
+        // (the four quads as four 128-bit values: read as one 64-byte vector, the register allocator kept the record as ONE 16-register
+        // tuple and spilled / reloaded the whole tuple around the slab test to keep its last quad, 64 + 128 bytes per trip)
+        float4 q0, q1, q2, q3;
+        fetch16x4<false, true>(tr.pairs, 4 * ref, q0, q1, q2, q3);
+        float dist_l, dist_r, exit_l, exit_r;
+        bool hit_l, hit_r;
+        ray_box_pair(o, inv, q0, q1, q2, h.t, hit_l, hit_r, dist_l, dist_r, exit_l, exit_r);
+        if (hit_l || hit_r) {
+          const bool first_l = ALL_OPAQUE ? (any_hit ? left_first<true>(dist_l, dist_r, exit_l, exit_r) : left_first<false>(dist_l, dist_r, exit_l, exit_r))
+                                          : left_first<false>(dist_l, dist_r, exit_l, exit_r);
+          const bool go_left = hit_l && (!hit_r || first_l);
+          if (hit_l && hit_r) {
+#if PT_STACK_CHILD  // the far side: the child itself, or (record, side)
+            const uint32_t e = ((go_left ? fbits(q3.z) : fbits(q3.x)) << 7) | (go_left ? fbits(q3.w) : fbits(q3.y));
+#else
+            const uint32_t e = (ref << 1) | (go_left ? 1u : 0u);
+#endif
+            if (sp != tr.stack_end) {
+              stack_store(sp, e);
+              sp += tr.stride;
+            } else {
+              deep[nd++] = e;
+            }
+          }
+          ref = go_left ? fbits(q3.x) : fbits(q3.z);
+          cnt = go_left ? fbits(q3.y) : fbits(q3.w);
+          need_pop = false;
+        }
+      }
+      if (need_pop) {
+        uint32_t e = 0;
+        if (nd != 0) {
+          e = deep[--nd];
+        } else if (sp == tr.stack) {
+          live = false;  // the walk is over
+        } else {
+          sp -= tr.stride;
+          e = stack_load(sp);
+        }
+        if (live) {
+#if PT_STACK_CHILD
+          ref = e >> 7;
+          cnt = e & 127u;
+#else
+          const uint2 c = fetch_child<false>(tr.pairs, e >> 1, e & 1u);
+          ref = c.x;
+          cnt = c.y;
+#endif
+        }
+      }
+    }
+    const bool parked = !live && cur != 0u;
+    const uint64_t parked_mask = __ballot(parked);
+    if (parked_mask != 0 && (__ballot(live) == 0 || static_cast<uint32_t>(__popcll(parked_mask)) >= kMergedPark)) {
+      if (parked) {
+        if (cur != 4u) {
+          float v;
+          if (ALL_OPAQUE || h.tri == kNoHit) v = h.tri == kNoHit ? 1.0f : 0.0f;  // nothing in the way / (all-opaque) any accepted triangle
+          else if (h.opq != 0u) v = 0.0f;                                       // the closest hit is provably opaque (main.comp:325)
+          else {
+            // the closest hit may be transparent (rare: cloth, glass): the reference's step-by-step walk goes on from this hit AFTER
+            // the loop, where its texture code does not sit among the walk's registers; the hit waits in `cold`
+            v = -1.0f;
+            const uint32_t at = COLD_HIT + 4u * (cur - 1u);
+            cold[at] = h.t;
+            cold[at + 1] = h.u;
+            cold[at + 2] = h.v;
+            cold[at + 3] = ubits(h.tri);
+          }
+          if (cur == 1u) vis0 = v;
+          else vis1 = v;
+        }
+        cur = 0;
+        if (todo) start();
+      }
+    }
+    if (__ballot(live) == 0) break;
+  }
+  if (!ALL_OPAQUE) {
+    // light samples whose first hit may be transparent: the rest of ray_scene_intersect_with_transparency (main.comp:306-332) from
+    // that hit on, lanes in lock step, then the caller's distance test (main.comp:447 / :487, which looks at the LAST step's hit)
+#pragma nounroll
+    for (uint32_t j = 0; j < 2u; ++j) {
+      float v = j ? vis1 : vis0;
+      if (v < 0.0f) {
+        const uint32_t at = COLD_HIT + 4u * j;
+        Hit sh{cold[at], cold[at + 1], cold[at + 2], fbits(cold[at + 3])};
+#if PT_MERGED_COLD
+        const vec3 so = cold_get(cold, COLD_ORIGIN), sdir = cold_get(cold, j ? COLD_L1 : COLD_L0);
+#else
+        const vec3 so = pend.origin, sdir = j ? pend.l1 : pend.l0;
+#endif
+        Tally t;
+        v = shadow_walk<false, false, TEXTURED, true>(sc, sd, tr, so, sdir, sh, t);
+        walks.rays += t.rays;
+        ext.visits += t.visits;
+        ext.tests += t.tests;
+        tally.hits += t.hits;
+        tally.taps += t.taps;
+        if (v != 0.0f && sh.tri != kNoHit) {
+          const float correction = lds_load16(stash.quad + 2u * j * stash.quad_stride).w;
+          const float limit = lds_load8(stash.pair + j * stash.pair_stride).y;
+          if (sh.t + correction < limit) v = 0.0f;
+        }
+      }
+      if (j) vis1 = v;
+      else vis0 = v;
+    }
+  }
+}
+
+// The colour update a DEFER vertex left behind (main.comp:536-552), now that its light samples' visibility is known; then the end of
+// the sample if the path ended there (main.comp:580-582, 607-612). Same expressions as k_shadow's.
+__device__ __forceinline__ void resolve_pending(const pt_dev_state& st, const Stash& stash, vec3 bg_linear, uint32_t slot, Pending& pend,
+                                                float vis0, float vis1, PathRegs& p, Tally& tally) {
+  if (!(pend.flags & PEND_SHADED)) return;
+  vec3 punctual = splat(0.0f), area_light = splat(0.0f);
+#pragma unroll
+  for (uint32_t j = 0; j < 2u; ++j) {
+    const float vis = j ? vis1 : vis0;
+    if ((pend.flags & (PEND_S0 << j)) && vis != 0.0f) {
+      const pt_f4 a = lds_load16(stash.quad + 2u * j * stash.quad_stride), b = lds_load16(stash.quad + (2u * j + 1u) * stash.quad_stride);
+      const float pdf = lds_load8(stash.pair + j * stash.pair_stride).x;
+      const vec3 c = mk(a.x, a.y, a.z) * vis * mk(b.x, b.y, b.z) * b.w / pdf;
+      if (pend.flags & (PEND_AREA0 << j)) area_light = c;
+      else punctual = punctual + c;
+      if (pend.flags & (PEND_TAP0 << j)) ++tally.taps;
+    }
+  }
+  vec3 direct = pend.emission;   // main.comp:536
+  direct = direct + punctual;    // :537
+  direct = direct + area_light;  // :538
+  p.color = p.color + direct * pend.af * pend.m;  // :545 / :552 (af == 1 for the opaque branch)
+  if (pend.flags & PEND_ENDED) {
+    float4 acc = st.accum[slot];
+    finish_sample(p.color, p.indirect, bg_linear, acc, tally);
+    st.accum[slot] = acc;
+    p.indirect = splat(1.0f);
+    p.color = splat(0.0f);
+  }
+  pend.flags = 0;
+}
 
 // The path kernel: every queued slot advances by up to `max_vertices` path vertices — extend,
 // shade (with its shadow walks), extend, ... — in ONE launch, its ray and path state held in
@@ -1468,6 +1850,116 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_paths(pt_dev_scene sc, pt_de
           if (!alive) break;
           o = next_o;
           d = next_d;
+        }
+        if (alive) {
+          st.ray_o[slot] = make_float4(o.x, o.y, o.z, 0.0f);
+          st.ray_d[slot] = make_float4(d.x, d.y, d.z, 0.0f);
+        }
+        st.path_a[slot] = make_float4(p.indirect.x, p.indirect.y, p.indirect.z, ubits(p.rng));
+        st.path_b[slot] = make_float4(p.color.x, p.color.y, p.color.z, ubits(ctr_pack(p.light_steps, p.transp_steps, primary, p.sample)));
+      }
+      const AppendSlots at = block_append2(alive, &st.counters[cnt_out], false, nullptr);
+      if (alive) st.queue[parity ^ 1u][at.a] = slot;
+    }
+  }
+  flush_tally(ext, st, PT_K_EXTEND);
+  flush_tally(tally, st, PT_K_SHADE);
+  flush_tally(walks, st, PT_K_SHADOW);
+}
+
+// k_paths for scenes read from global memory with at most two light samples per vertex: same state, same queues, same per-slot
+// order of work, but a vertex's shadow walks ride with the next vertex's closest-hit walk in one loop (merged_walk). The last
+// vertex a slot shades in a launch leaves light samples behind: one more round walks those alone, so nothing pends across launches.
+template <bool ALL_OPAQUE, int MIN_WAVES, bool TEXTURED>
+__global__ __launch_bounds__(256, MIN_WAVES) void k_paths_merged(pt_dev_scene sc, pt_dev_frame f, pt_dev_state st, uint32_t parity,
+                                                                          uint32_t cnt_in, uint32_t cnt_out, uint32_t cnt_zero,
+                                                                          uint32_t max_vertices, uint32_t xcd_chunk) {
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
+  const uint32_t n = st.counters[cnt_in];
+  if (blockIdx.x == 0 && threadIdx.x == 0) st.counters[cnt_zero] = 0;
+  Tally ext, tally, walks;
+  const uint32_t n_lights = sc.directional_light_count + sc.point_light_count + (f.pc.emissive_triangle_count ? 1u : 0u);
+  const vec3 bg_linear = mk(f.bg_linear[0], f.bg_linear[1], f.bg_linear[2]);
+  uint32_t vblock = blockIdx.x;
+  if (xcd_chunk) {
+    const uint32_t x = blockIdx.x & 7u, i = blockIdx.x >> 3;
+    vblock = ((i / xcd_chunk) * 8u + x) * xcd_chunk + i % xcd_chunk;
+  }
+  if (vblock * blockDim.x < n) {  // block-uniform
+    const Tracer tr = make_tracer<false>(sc, lds_dyn);
+    const ShadeData sd = make_shade_data<false>(sc, tr, lds_dyn);
+    // LDS: [stack rows x blockDim words | stash: 4 quads x blockDim | 2 pairs x blockDim]
+    const uint32_t rows = sc.lds_stack_levels ? sc.lds_stack_levels : sc.stack_entries;
+    const uint32_t stash_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_dyn + static_cast<size_t>(blockDim.x) * rows));
+    const Stash stash{stash_base + 16u * threadIdx.x, 16u * blockDim.x, stash_base + 64u * blockDim.x + 8u * threadIdx.x, 8u * blockDim.x};
+    for (uint32_t base = vblock * blockDim.x; base < n; base += gridDim.x * blockDim.x) {  // block-uniform trip count
+      const uint32_t gid = base + threadIdx.x;
+      bool alive = false;
+      uint32_t slot = 0;
+      if (gid < n) {
+        slot = st.queue[parity][gid];
+        const float4 o4 = st.ray_o[slot], d4 = st.ray_d[slot];
+        const float4 pa = st.path_a[slot], pb = st.path_b[slot];
+        const uint32_t ctr = fbits(pb.w);
+        PathRegs p{xyz(pa), xyz(pb), fbits(pa.w), ctr_light(ctr), ctr_transp(ctr), ctr_sample(ctr)};
+        bool primary = ctr_primary(ctr);
+        vec3 o = xyz(o4), d = xyz(d4);
+        Pending pend;
+        pend.origin = pend.l0 = pend.l1 = pend.emission = pend.m = splat(0.0f);
+        pend.af = 1.0f;
+        float vis0 = 0.0f, vis1 = 0.0f;
+        bool has_ray = true;
+        volatile float cold[COLD_WORDS];
+        for (uint32_t k = 0;; ++k) {  // bounded: at most max_vertices + 1 rounds, every wave reaches the end of the grid
+#if PT_MERGED_COLD
+          // park what the walk does not need (see merged_walk) ...
+          cold_put(cold, COLD_INDIRECT, p.indirect);
+          cold_put(cold, COLD_COLOR, p.color);
+          cold[COLD_RNG] = ubits(p.rng);
+          cold[COLD_CTR] = ubits(ctr_pack(p.light_steps, p.transp_steps, false, p.sample));
+          cold_put(cold, COLD_EMISSION, pend.emission);
+          cold_put(cold, COLD_M, pend.m);
+          cold[COLD_AF] = pend.af;
+          cold_put(cold, COLD_ORIGIN, pend.origin);
+          cold_put(cold, COLD_L0, pend.l0);
+          cold_put(cold, COLD_L1, pend.l1);
+          cold_put(cold, COLD_RAY_O, o);
+          cold_put(cold, COLD_RAY_D, d);
+#endif
+          Hit h{kInfinity, 0.0f, 0.0f, kNoHit};
+          merged_walk<ALL_OPAQUE, TEXTURED>(sc, sd, tr, stash, pend, has_ray, o, d, cold, h, vis0, vis1, ext, walks, tally);
+#if PT_MERGED_COLD
+          // ... and take it back
+          p.indirect = cold_get(cold, COLD_INDIRECT);
+          p.color = cold_get(cold, COLD_COLOR);
+          p.rng = fbits(cold[COLD_RNG]);
+          {
+            const uint32_t c = fbits(cold[COLD_CTR]);
+            p.light_steps = ctr_light(c);
+            p.transp_steps = ctr_transp(c);
+            p.sample = ctr_sample(c);
+          }
+          pend.emission = cold_get(cold, COLD_EMISSION);
+          pend.m = cold_get(cold, COLD_M);
+          pend.af = cold[COLD_AF];
+          d = cold_get(cold, COLD_RAY_D);
+#endif
+          resolve_pending(st, stash, bg_linear, slot, pend, vis0, vis1, p, tally);
+          if (!has_ray) break;
+          if (primary) st.primary_id[slot] = h.tri;
+          primary = false;
+          vec3 next_o = mk(0, 0, 0), next_d = mk(0, 0, 0);
+          bool shaded;
+          alive = shade_vertex<false, ALL_OPAQUE, false, true, TEXTURED, true>(sc, sd, f, st, tr, n_lights, bg_linear, slot, h, d, p, next_o,
+                                                                              next_d, tally, walks, shaded, &pend, &stash);
+          if (alive) {
+            o = next_o;
+            d = next_d;
+          }
+          if (!alive || k + 1 >= max_vertices) {  // no further ray in this launch: one more round if light samples are left over
+            has_ray = false;
+            if (!pend.flags) break;
+          }
         }
         if (alive) {
           st.ray_o[slot] = make_float4(o.x, o.y, o.z, 0.0f);
@@ -1632,20 +2124,54 @@ void launch_paths(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_st
     else if (punctual) PT_LAUNCH_PATHS(true, B, PT_PATHS_MIN_WAVES, true, false);  \
     else PT_LAUNCH_PATHS(true, B, PT_PATHS_MIN_WAVES_PLAIN, false, false);         \
   } while (0)
+  // (scenes in global memory: no texture -> the kernel without the six inlined copies of the sampler: half the code (57 -> ~30 KB;
+  // the instruction cache is 64 KB per two CUs and the generic kernel's waves wait for instructions 10 % of their time) and
+  // fewer registers to spill)
+#define PT_LAUNCH_PATHS_GLOBAL(B)                                                            \
+  do {                                                                                       \
+    if (big && textured) PT_LAUNCH_PATHS(false, B, PT_PATHS_MIN_WAVES_GLOBAL, true, true);   \
+    else if (big) PT_LAUNCH_PATHS(false, B, PT_PATHS_MIN_WAVES_GLOBAL, true, false);         \
+    else if (textured) PT_LAUNCH_PATHS(false, B, PT_PATHS_MIN_WAVES, true, true);            \
+    else PT_LAUNCH_PATHS(false, B, PT_PATHS_MIN_WAVES, true, false);                         \
+  } while (0)
   switch (variant) {
     case 3: PT_LAUNCH_PATHS_LDS(true); break;
     case 2: PT_LAUNCH_PATHS_LDS(false); break;
-    case 1:
-      if (big) PT_LAUNCH_PATHS(false, true, PT_PATHS_MIN_WAVES_GLOBAL, true, true);
-      else PT_LAUNCH_PATHS(false, true, PT_PATHS_MIN_WAVES, true, true);
-      break;
-    default:
-      if (big) PT_LAUNCH_PATHS(false, false, PT_PATHS_MIN_WAVES_GLOBAL, true, true);
-      else PT_LAUNCH_PATHS(false, false, PT_PATHS_MIN_WAVES, true, true);
-      break;
+    case 1: PT_LAUNCH_PATHS_GLOBAL(true); break;
+    default: PT_LAUNCH_PATHS_GLOBAL(false); break;
   }
+#undef PT_LAUNCH_PATHS_GLOBAL
 #undef PT_LAUNCH_PATHS_LDS
 #undef PT_LAUNCH_PATHS
+}
+
+// k_paths_merged: scenes read from global memory, at most two light samples per vertex (the caller checks both). LDS per thread:
+// the traversal-stack rows + 80 bytes of stash.
+size_t merged_lds_bytes(const pt_dev_scene& sc, uint32_t block) { return trace_lds_bytes(sc, block) + 80u * static_cast<size_t>(block); }
+
+void launch_paths_merged(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity, uint32_t cnt_in,
+                         uint32_t cnt_out, uint32_t cnt_zero, uint32_t max_entries, uint32_t block, uint32_t max_blocks,
+                         uint32_t max_vertices, uint32_t xcd_chunk, hipStream_t s) {
+  uint32_t grid = blocks_for(max_entries, block);
+  if (grid > max_blocks) grid = max_blocks;
+  if (xcd_chunk) {  // whole rounds of 8 chunks
+    if (xcd_chunk > (grid + 7u) / 8u) xcd_chunk = (grid + 7u) / 8u;
+    const uint32_t round = 8u * xcd_chunk;
+    grid = (grid + round - 1u) / round * round;
+  }
+  const size_t lds = merged_lds_bytes(sc, block);
+  const bool textured = sc.any_texture != 0;
+#define PT_LAUNCH_MERGED(B, W, T) \
+  hipLaunchKernelGGL((k_paths_merged<B, W, T>), dim3(grid), dim3(block), lds, s, sc, f, st, parity, cnt_in, cnt_out, cnt_zero, max_vertices, xcd_chunk)
+#define PT_LAUNCH_MERGED_BY_SIZE(B)                                      \
+  do {                                                                   \
+    if (textured) PT_LAUNCH_MERGED(B, PT_MERGED_MIN_WAVES, true);        \
+    else PT_LAUNCH_MERGED(B, PT_MERGED_MIN_WAVES, false);                \
+  } while (0)
+  if (sc.all_opaque) PT_LAUNCH_MERGED_BY_SIZE(true);
+  else PT_LAUNCH_MERGED_BY_SIZE(false);
+#undef PT_LAUNCH_MERGED_BY_SIZE
+#undef PT_LAUNCH_MERGED
 }
 
 #ifndef PT_FAST_ARITH

@@ -26,7 +26,7 @@ oracle_lib.render(O, packed, rp, threads=1, rows=(y, y + rows), want_ids=False, 
 n = O.orc_trip_log_length()
 O.orc_set_trip_log(None, 0)
 t = log[:n]
-trips = (t & 0x3FFFFFFF).astype(np.int64)
+trips = (t & 0x1FFFFFFF).astype(np.int64)
 closest, walk, ended = (t >> 31) == 0, (t >> 31) == 1, ((t >> 30) & 3) == 3
 total = trips.sum()
 print(f"{name}: {n} traversals, {total} trips")

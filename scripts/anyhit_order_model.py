@@ -19,7 +19,8 @@ rp = packed.render_params(L, w, h, spp, bench.BG.get(name, (0.239,) * 3), bench.
 y = h // 2
 ref = base = None
 print(f"{name}: rows {y}..{y + rows}, {spp} spp, own triangle first (ORC_FLAG_SELF_FIRST) in every line")
-for order, label in enumerate(("nearer first (as now)", "farther first", "larger box first", "smaller box first", "leaf before inner node")):
+for order, label in enumerate(("nearer first (as now)", "farther first", "larger box first", "smaller box first", "leaf before inner node",
+                               "longer span first", "shorter span first", "larger t_far first", "leaf first, else farther", "relative span first", "unclamped span first")):
     O.orc_set_anyhit_order(order)
     _, accum, ids, st = oracle_lib.render(O, packed, rp, threads=8, rows=(y, y + rows), flags=oracle_lib.GPU_MIRROR | 4)
     a = accum[y:y + rows].view(np.uint32).copy()

@@ -34,7 +34,7 @@ n = O.orc_trip_log_length()
 O.orc_set_trip_log(None, 0)
 t = log[:n].reshape(-1, 2)
 t = t[(t[:, 0] >> 31) == 0]  # closest-hit traversals only
-trips, pixel, depth = (t[:, 0] & 0x3FFFFFFF).astype(np.int64), (t[:, 1] >> 4).astype(np.int64), (t[:, 1] & 15).astype(np.int64)
+trips, pixel, depth = (t[:, 0] & 0x1FFFFFFF).astype(np.int64), (t[:, 1] >> 4).astype(np.int64), (t[:, 1] & 15).astype(np.int64)
 print(f"{name}: {trips.size} closest-hit traversals of {8 * tile_rows} rows at {spp} spp, mean {trips.mean():.1f} trips, max {trips.max()}")
 
 # per pixel: its traversals in order -> (pixels, phases) arrays padded with -1 (the pixel has finished all its samples)

@@ -26,8 +26,8 @@ oracle_lib.render(O, packed, rp, threads=1, rows=(y, y + rows), want_ids=False, 
 n = O.orc_trip_log_length()
 O.orc_set_trip_log(None, 0)
 t = log[:n]
-closest = (t[(t >> 31) == 0] & 0x3FFFFFFF).astype(np.int64)
-anyhit = (t[(t >> 31) == 1] & 0x3FFFFFFF).astype(np.int64)
+closest = (t[(t >> 31) == 0] & 0x1FFFFFFF).astype(np.int64)
+anyhit = (t[(t >> 31) == 1] & 0x1FFFFFFF).astype(np.int64)
 print(f"{name}: {closest.size} closest-hit traversals (mean {closest.mean():.1f} trips, max {closest.max()}), "
       f"{anyhit.size} any-hit walks (mean {anyhit.mean() if anyhit.size else 0:.1f})")
 rng = np.random.RandomState(1)

@@ -39,7 +39,7 @@ class OracleBackend:
         self.rgba = torch.zeros(pixels, dtype=torch.int32)
 
     def render(self, rp, stats, want_ids=False):
-        _, accum, ids, st = oracle_lib.render(self.oracle, self.packed, rp, threads=2, flags=oracle_lib.GPU_MIRROR)
+        _, accum, ids, st = oracle_lib.render(self.oracle, self.packed, rp, threads=2, flags=oracle_lib.GPU_MIRROR_LDS)  # the test scene is LDS-sized
         self.accum.copy_(torch.from_numpy(accum.reshape(-1)))
         self.ids.copy_(torch.from_numpy(ids.reshape(-1).view(np.int32)))
         if stats is not None:

@@ -65,15 +65,21 @@ def test_bench_script_refuses_a_world_size_mismatch():
 
 @pytest.mark.gpu
 def test_bench_script_on_the_gpu_verifies_the_frame_it_times():
-    """The driver's command with fewer steps: the headline config (cfg2, full size) plus cfg1; the timed frame must equal
-    the committed oracle digest, the oracle band must equal the GPU frame, and no roofline fraction may pass 1."""
-    j = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--configs", "cube512"], timeout=900)
-    _check_contract(j, 1, 2, 1)
-    assert j["frame_verified"] is True and j["frame_properties_ok"] is True
-    assert j["cpu_baseline"]["gpu_band_bit_exact"] is True
+    """The driver's command with fewer steps: the headline config (cfg3: the atrium at 1080p, 256 spp) plus cfg2 and cfg1. The
+    timed frames must equal the committed oracle digests (cfg3: a 32-row band at its own sample count; cfg2: the whole frame
+    with its counters), the oracle band timed beside them must equal the GPU frame, and no roofline fraction may pass 1."""
+    j = _run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--configs", "cornell1080,cube512"], timeout=900)
+    _check_contract(j, 1, 1, 0)
+    assert "cfg3" in j["config"]["workload"] and j["config"]["name"] == "atrium1080" and j["config"]["sample_count"] == 256
+    assert j["frame_verified"] is True and j["frame_properties_ok"] is True and j["frame_verified_rows"][1] - j["frame_verified_rows"][0] >= 32
+    cb = j["cpu_baseline"]
+    assert cb["gpu_band_bit_exact"] is True and cb["kind"] == "port" and cb["lavapipe"].startswith("unavailable (")
+    assert cb["cores"] == cb["threads"] <= cb["host"]["affinity_cores"] and cb["single_thread"]["value"] > 0
     r = j["roofline"]
-    assert r["bound"] == "valu" and 0 < r["frac"] <= 1 and r["served_from"] == "lds"
-    (cube,) = j["configs"]
+    assert r["bound"] == "hbm" and 0 < r["frac"] <= 1 and r["unit"] == "GB/s"
+    cornell, cube = j["configs"]
+    assert cornell["name"] == "cornell1080" and cornell["frame_verified"] is True and cornell["cpu_baseline"]["gpu_band_bit_exact"] is True
+    assert cornell["roofline"]["bound"] == "valu" and 0 < cornell["roofline"]["frac"] <= 1 and cornell["roofline"]["served_from"] == "lds"
     assert cube["name"] == "cube512" and cube["frame_properties_ok"] is True and cube["cpu_baseline"]["gpu_band_bit_exact"] is True
     assert 0 < cube["roofline"]["frac"] <= 1
 
@@ -85,8 +91,8 @@ def test_bench_script_rccl_leg_on_a_one_rank_group():
     frame of one rank is that rank's frame, so the committed cfg2 digest still has to match."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29655", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1",
                PT_BENCH_FORCE_COLLECTIVES="1")
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--configs", "none",
-                        "--no-cpu-baseline", "--no-fast-arith"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "cornell1080", "--steps", "2", "--warmup", "1",
+                        "--configs", "none", "--no-cpu-baseline", "--no-fast-arith"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     (line,) = [l for l in p.stdout.splitlines() if l.startswith("{")]
     j = json.loads(line)

@@ -5,6 +5,8 @@ the oracle; everything else — geometry, texel pool, resolution, tree depth, ke
 Checks: size-independent properties of the whole frame, a band of rows against the oracle bit for bit, and the
 wavefront pipeline's frame equal to the path pipeline's."""
 import hashlib
+import json
+import os
 
 import numpy as np
 import pytest
@@ -76,6 +78,38 @@ def test_full_size_scene_at_1080p(oracle, monkeypatch, factory, kwargs, spp, dep
     assert d2 == digest
     for k in COUNTERS:
         assert st[k] == st2[k], k
+
+
+@pytest.mark.parametrize("name", ["atrium1080", "rocks1080"])
+def test_cfg3_cfg4_at_their_own_sample_counts_equal_the_oracle_band_digest(monkeypatch, name):
+    """cfg3 / cfg4 exactly as bench.py renders them — full scene, 1080p, 256 / 484 strata, the bench seed — against the committed
+    oracle digest of a 32-row band (tests/golden/make_band_digest.py), with the frame rendered as one, two (the default) and three
+    concurrent bands: hundreds of regenerations per slot, the long drain and the bands' interleaved launches, which 9 / 4 spp
+    do not exercise."""
+    import bench
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"{name}_full_digest.json")))
+    factory, kw, w, h, spp, _ = bench.WORKLOADS[name]
+    assert (gold["width"], gold["height"], gold["sample_count"], gold["seed"]) == (w, h, spp, bench.SEED)
+    y0, y1 = gold["rows"]
+    assert y1 - y0 >= 32
+    eff = int(np.sqrt(np.float32(spp))) ** 2
+    packed = None
+    for bands in ("2", "1", "3"):
+        monkeypatch.setenv("PT_CONCURRENT_BANDS", bands)
+        r = Renderer(0)  # the context reads the knob at creation
+        try:
+            if packed is None:
+                packed = r.pack(getattr(scenes, factory)(**kw))
+            r.upload(packed)
+            rp = packed.render_params(r.lib, w, h, spp, bench.BG[name], seed=bench.SEED)
+            rgba, accum, ids, st = r.render_params(rp)
+        finally:
+            r.close()
+        if bands == "2":
+            properties(accum, rgba, st, w, h, eff)
+        assert hashlib.sha256(np.ascontiguousarray(accum[y0:y1]).tobytes() + np.ascontiguousarray(ids[y0:y1]).tobytes()).hexdigest() == \
+            gold["sha256_accum_then_ids"], bands
+        assert hashlib.sha256(np.ascontiguousarray(rgba[y0:y1]).tobytes()).hexdigest() == gold["sha256_rgba8"], bands
 
 
 def test_cfg5_shape_4k_4096_strata(oracle):

@@ -41,7 +41,7 @@ def compare(renderer, oracle, scene, w, h, spp, seed, rank=0, num_ranks=1, rows=
     assert not mism.any(), f"{mism.any(axis=-1).sum()} pixels differ; first {np.argwhere(mism)[:3]}"
     assert (rgba[sl] == o_rgba[sl]).all()
     if rows is None:
-        o_st = oracle_lib.render(oracle, packed, rp, threads=8, flags=oracle_lib.GPU_MIRROR)[3]
+        o_st = oracle_lib.render(oracle, packed, rp, threads=8, flags=oracle_lib.mirror_flags(st["scene_in_lds"]))[3]
         for k in COUNTERS:
             assert st[k] == o_st[k], (k, st[k], o_st[k])
     return st
@@ -128,10 +128,11 @@ def test_rank_split_matches_oracle_per_rank(renderer, oracle):
                                  {"PT_BAND_SLOTS": "4096"}, {"PT_BAND_SLOTS": "4096", "PT_PIPELINE": "wavefront"},
                                  {"PT_XCD_CHUNK": "5"}, {"PT_XCD_CHUNK": "100000", "PT_PATHS_BLOCKS": "24"},
                                  {"PT_LDS_STACK": "2"}, {"PT_LDS_STACK": "3", "PT_PIPELINE": "wavefront"}, {"PT_LDS_STACK": "0"},
-                                 {"PT_PIPELINE": "wavefront", "PT_SORT_RAYS": "1", "PT_SORT_SHADOW": "1"},
                                  {"PT_CONCURRENT_BANDS": "3", "PT_BAND_MIN_TILES": "1"},
                                  {"PT_CONCURRENT_BANDS": "7", "PT_BAND_MIN_TILES": "1", "PT_PATHS_VERTICES": "5"},
                                  {"PT_CONCURRENT_BANDS": "1"}, {"PT_CHILD_ENTRIES": "0"},
+                                 {"PT_MERGED": "0"}, {"PT_MERGED_LDS_STACK": "2"}, {"PT_MERGED_LDS_STACK": "0", "PT_PATHS_VERTICES": "3"},
+                                 {"PT_CHILD_ENTRIES": "0", "PT_MERGED_LDS_STACK": "3", "PT_PATHS_BLOCK_THREADS": "256"},
                                  {"PT_CHILD_ENTRIES": "0", "PT_PIPELINE": "wavefront", "PT_LDS_STACK": "3"}])
 def test_alternative_pipelines_give_the_same_bits(oracle, monkeypatch, env):
     """The wavefront pipeline (k_extend + k_shade, fused or with the split k_shadow, lazy or per-iteration

@@ -140,3 +140,31 @@ def test_reference_work_group_size(ptlib):
     for (w, h, ex, ey) in [(512, 512, 32, 32), (1920, 1080, 32, 16), (1080, 1920, 16, 32)]:
         ptlib.pt_reference_work_group_size(C.c_uint32(w), C.c_uint32(h), C.byref(x), C.byref(y))
         assert (x.value, y.value) == (ex, ey)
+
+
+def test_pt_create_multi_without_rccl_fails_cleanly():
+    """on a machine without librccl, pt_create_multi must return NULL with a message, not crash (the dlopen failure
+    path called dlerror() twice and built a std::string from NULL). PT_RCCL_LIB points the loader at a file that does not exist;
+    a fresh process, because the library caches the loaded API. Also: ids are normalised before the duplicate check."""
+    import subprocess
+    import sys
+    code = """
+import ctypes as C, sys
+sys.path.insert(0, %r)
+from pathtracer_amd import lib
+L = lib.load()
+L.pt_create_multi.restype = C.c_void_p
+L.pt_last_error.restype = C.c_char_p
+L.pt_last_error.argtypes = [C.c_void_p]
+ids = (C.c_int * 2)(-1, 0)
+assert L.pt_create_multi(ids, 2) is None
+assert b"listed twice" in L.pt_last_error(None), L.pt_last_error(None)
+ids = (C.c_int * 2)(0, 1)
+assert L.pt_create_multi(ids, 2) is None
+msg = L.pt_last_error(None)
+assert b"librccl.so not found" in msg and b"no_such_rccl" in msg, msg
+print("ok")
+""" % ROOT
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PT_RCCL_LIB="/nonexistent/no_such_rccl.so", PT_NO_TORCH_PRELOAD="1"),
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and "ok" in p.stdout, p.stderr[-2000:]

@@ -48,29 +48,50 @@ def test_anyhit_checker_mode_gives_identical_images(oracle):
         assert b[3]["node_visits"] <= a[3]["node_visits"] and b[3]["tri_tests"] <= a[3]["tri_tests"]
 
 
-def test_experimental_shadow_shortcuts_give_identical_images(oracle):
-    """Two experiments no kernel implements yet: an any-hit shadow query that first tests the triangle its
-    shading point lies on (ORC_FLAG_SELF_FIRST: a light behind the surface sends the ray straight back through it), and any-hit
-    walks that enter two hit children in another order. All-opaque scenes only; the frames must not change by a bit."""
-    self_first = 4
+def test_shadow_shortcuts_give_identical_images(oracle):
+    """The HIP path's exact shadow-ray savings on all-opaque scenes, as the oracle's checker modes mirror them: an any-hit shadow
+    query first tests the triangle its shading point lies on (ORC_FLAG_SELF_FIRST: a light behind the surface sends the ray straight
+    back through it), and any-hit walks enter two hit children in another order (ORC_FLAG_ANYHIT_SPAN_ORDER, plus the experiment
+    switch's other orders). The frames must not change by a bit; only the work counters may."""
+    M = oracle_lib
     for s in [scenes.cornell_scene(with_point_light=True, with_directional_light=True), scenes.soup_scene(3000, seed=4, emissive_every=40),
               scenes.rocks_scene(n_tris=6000)]:
         p = PackedScene(s, oracle, "orc_")
         assert oracle.orc_scene_all_opaque(C.byref(p.desc)) == 1
         rp = p.render_params(oracle, 64, 48, 9, seed=23, prefix="orc_")
         a = oracle_lib.render(oracle, p, rp)
-        b = oracle_lib.render(oracle, p, rp, flags=oracle_lib.GPU_MIRROR)
+        b = oracle_lib.render(oracle, p, rp, flags=M.ANYHIT_OPAQUE_SHADOW | M.CULL_BEHIND)
         try:
-            for order in range(5):
+            for order in range(11):
                 oracle.orc_set_anyhit_order(order)
-                c = oracle_lib.render(oracle, p, rp, flags=oracle_lib.GPU_MIRROR | self_first)
-                assert a[1].tobytes() == c[1].tobytes() and a[0].tobytes() == c[0].tobytes() and (a[2] == c[2]).all()
-                for k in ("paths", "rays", "shaded_vertices", "nan_samples"):
-                    assert a[3][k] == c[3][k]
-                if order == 0:
-                    assert c[3]["rays_shadow_shortcut"] > b[3]["rays_shadow_shortcut"] and c[3]["node_visits"] < b[3]["node_visits"]
+                for flags in (M.ANYHIT_OPAQUE_SHADOW | M.CULL_BEHIND | M.SELF_FIRST, M.GPU_MIRROR):
+                    c = oracle_lib.render(oracle, p, rp, flags=flags)
+                    assert a[1].tobytes() == c[1].tobytes() and a[0].tobytes() == c[0].tobytes() and (a[2] == c[2]).all()
+                    for k in ("paths", "rays", "shaded_vertices", "nan_samples"):
+                        assert a[3][k] == c[3][k]
+                    if order == 0:
+                        assert c[3]["rays_shadow_shortcut"] > b[3]["rays_shadow_shortcut"] and c[3]["node_visits"] < b[3]["node_visits"]
         finally:
             oracle.orc_set_anyhit_order(0)
+
+
+def test_opaque_triangle_shortcut_gives_identical_images(oracle):
+    """ORC_FLAG_OPAQUE_TRIANGLES (scenes that are NOT all-opaque): a shadow-walk step whose closest hit lies on a provably opaque
+    triangle returns 0 without fetching attributes, material and texture. Same frames; fewer hits_shaded / texture_taps."""
+    M = oracle_lib
+    saved = 0
+    for s in [scenes.cornell_scene(True, True, True, True), scenes.textured_scene(), scenes.atrium_scene(detail=2, tex_size=32),
+              scenes.random_scene(7), scenes.random_scene(12)]:
+        p = PackedScene(s, oracle, "orc_")
+        rp = p.render_params(oracle, 64, 48, 9, seed=29, prefix="orc_")
+        a = oracle_lib.render(oracle, p, rp)
+        b = oracle_lib.render(oracle, p, rp, flags=M.OPAQUE_TRIANGLES)
+        assert a[1].tobytes() == b[1].tobytes() and a[0].tobytes() == b[0].tobytes() and (a[2] == b[2]).all()
+        for k in ("paths", "rays", "node_visits", "tri_tests", "shaded_vertices", "nan_samples", "rays_shadow_walked"):
+            assert a[3][k] == b[3][k], k
+        assert b[3]["hits_shaded"] <= a[3]["hits_shaded"] and b[3]["texture_taps"] <= a[3]["texture_taps"]
+        saved += a[3]["hits_shaded"] - b[3]["hits_shaded"]
+    assert saved > 0
 
 
 def test_behind_origin_cull_checker_mode_gives_identical_images(oracle):

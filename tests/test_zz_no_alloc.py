@@ -44,6 +44,18 @@ def test_noalloc_entry_point_matches_the_allocating_one_twice_in_a_row():
             a_ref, i_ref, st_ref = _render(r, "pt_render_accum_device", rp)
             a, i, st = _render(r, "pt_render_accum_device_noalloc", rp)
             assert (a == a_ref).all() and (i == i_ref).all()
+            # "allocates nothing", looked at from outside: with the outputs already allocated, the device's free memory is the same
+            # before and after a call (hipMemGetInfo through torch; torch's own caching allocator is not involved in the call)
+            import torch
+            pixels = w * h
+            accum = torch.empty(pixels * 4, dtype=torch.float32, device="cuda:0")
+            torch.cuda.synchronize()
+            free_before = torch.cuda.mem_get_info(0)[0]
+            rc = r.lib.pt_render_accum_device_noalloc(r.ctx, C.byref(rp), C.c_void_p(accum.data_ptr()), None, None, None)
+            r._check(rc, "pt_render_accum_device_noalloc")
+            torch.cuda.synchronize()
+            assert torch.cuda.mem_get_info(0)[0] == free_before
+            assert (accum.cpu().numpy().view(np.uint32) == a_ref).all()
             for k in COUNTERS:
                 assert st[k] == st_ref[k], k
             assert st["rays"] == st["rays_closest"] + st["rays_shadow_walked"] + st["rays_shadow_shortcut"]
