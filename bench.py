@@ -512,8 +512,10 @@ def fast_arith_leg(name: str, steps: int, exact_frame, exact_value: float) -> di
     rp = packed.render_params(be.lib, width, height, spp, BG.get(name, (0.239, 0.239, 0.239)), SEED)
     be.alloc(width * height)
     stats = abi.Stats()
+    t0 = time.perf_counter()
     be.render(rp, stats)  # warm-up
     be.sync()
+    steps = max(1, min(steps, int(20.0 / max(time.perf_counter() - t0, 1e-3))))  # a side leg: about 20 s of frames at most
     t0 = time.perf_counter()
     rays = 0
     for _ in range(steps):

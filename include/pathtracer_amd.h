@@ -235,6 +235,8 @@ typedef struct pt_stats {
   uint64_t merged_walk;          /* 1: the path kernel was k_paths_merged (scene in global memory, at most two light samples
                                     per vertex): a vertex's shadow walks ride with the next closest-hit walk; all traversal
                                     work is then counted in the `extend` slice                                   */
+  uint64_t bvh_wide4;            /* 1: PT_BVH=wide4 was in effect (opt-in, NOT bit-exact): node_visits counts visits of
+                                    64-byte records of up to four children with 8-bit boxes                       */
 } pt_stats;
 
 #define PT_FLAG_TIME_KERNELS 1u /* bracket every kernel with HIP events (serialises; for profiling) */

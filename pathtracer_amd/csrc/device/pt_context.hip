@@ -7,6 +7,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types and enums only: the functions are resolved with dlsym when pt_create_multi first needs them
 
+#include <array>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -153,6 +154,7 @@ struct pt_ctx {
   uint32_t lds_stack = 16;          // PT_LDS_STACK: traversal-stack rows in LDS per lane for scenes in global memory (0 = the whole depth).
                                     // 16 rows + private-memory overflow: the 4.7 M-triangle rocks (depth 33) go from 4 to 7 k_extend waves
                                     // per SIMD (-21 % k_extend time) and k_paths +5 %; shallower trees are unaffected (measured)
+  bool wide4 = false;               // PT_BVH=wide4 (opt-in, NOT bit-exact): k_paths_merged walks 64-byte records of up to four children with 8-bit boxes
   bool merged = true;               // PT_MERGED=0: scenes in global memory with at most two light samples per vertex run k_paths (shadow walks in
                                     // their own phase) instead of k_paths_merged (a vertex's shadow walks ride with the next closest-hit walk)
   uint32_t merged_lds_stack = 9;    // PT_MERGED_LDS_STACK: LDS stack rows per lane of k_paths_merged, deeper rows in private memory. 36 B + 80 B of stash per
@@ -444,6 +446,7 @@ extern "C" pt_ctx* pt_create(int device) {
   if (ctx->lds_stack > 64) ctx->lds_stack = 64;  // 256 threads x 64 rows x 4 B = the 64 KiB a workgroup may ask for
   if (const char* e = std::getenv("PT_CHILD_ENTRIES")) ctx->child_entries = std::atoi(e) != 0;
   if (const char* e = std::getenv("PT_MERGED")) ctx->merged = std::atoi(e) != 0;
+  if (const char* e = std::getenv("PT_BVH")) ctx->wide4 = std::string(e) == "wide4";
   if (const char* e = std::getenv("PT_MERGED_LDS_STACK")) ctx->merged_lds_stack = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   if (ctx->merged_lds_stack > 64) ctx->merged_lds_stack = 64;
   if (const char* e = std::getenv("PT_CONCURRENT_BANDS")) ctx->concurrent_bands = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
@@ -550,6 +553,125 @@ extern "C" int pt_upload_scene(pt_ctx* ctx, const pt_scene_desc* s) {
   }
   return PT_OK;
 }
+
+namespace {
+
+// PT_BVH=wide4: the reference's binary tree collapsed into records of up to four children (pt_kernels.hip, wide_visit). A record
+// starts from a binary inner node's two children and replaces the inner child with the largest box by its own two children until
+// four are held or only leaves are left. Child boxes are stored as bytes on a per-record grid (common origin = the union's lower
+// corner, per-axis power-of-two cell), rounded OUTWARDS and checked with the float arithmetic a decoder would use, so every stored
+// box contains the reference's. Entries are (ref << 7 | cnt) like the kernels' stack entries (the caller checks packed_stack).
+struct WideRecord {
+  float origin[3];
+  uint32_t exps;
+  uint32_t entry[4];
+  uint32_t lo[3], hi_x;
+  uint32_t hi_y, hi_z, pad[2];
+};
+static_assert(sizeof(WideRecord) == 64, "layout");
+
+void build_wide(const pt_scene_desc* s, std::vector<WideRecord>& rec, uint32_t& stack_need) {
+  const pt_packed_bvh_node* N = s->bvh_nodes;
+  rec.clear();
+  stack_need = 0;
+  if (N[0].triangle_count != 0) return;  // a single leaf: nothing to collapse
+  auto area = [&](uint32_t n) {
+    const float dx = N[n].aabb_max[0] - N[n].aabb_min[0], dy = N[n].aabb_max[1] - N[n].aabb_min[1], dz = N[n].aabb_max[2] - N[n].aabb_min[2];
+    return dx * dy + dy * dz + dz * dx;
+  };
+  std::vector<uint32_t> order{0u};            // the binary inner node each wide record starts from, breadth-first
+  std::vector<std::array<uint32_t, 4>> kid_wide;  // per record: wide index of an inner child, 0xFFFFFFFF for a leaf or an empty place
+  std::vector<uint32_t> kid_count;
+  for (size_t head = 0; head < order.size(); ++head) {
+    uint32_t kids[4] = {N[order[head]].left_or_begin, N[order[head]].left_or_begin + 1u, 0u, 0u};
+    uint32_t nk = 2;
+    while (nk < 4) {
+      int best = -1;
+      for (uint32_t k = 0; k < nk; ++k)
+        if (N[kids[k]].triangle_count == 0 && (best < 0 || area(kids[k]) > area(kids[best]))) best = static_cast<int>(k);
+      if (best < 0) break;
+      const uint32_t c = N[kids[best]].left_or_begin;
+      kids[best] = c;
+      kids[nk++] = c + 1u;
+    }
+    WideRecord r{};
+    float lo_u[3], hi_u[3];
+    for (int a = 0; a < 3; ++a) {
+      lo_u[a] = N[kids[0]].aabb_min[a];
+      hi_u[a] = N[kids[0]].aabb_max[a];
+      for (uint32_t k = 1; k < nk; ++k) {
+        lo_u[a] = std::fmin(lo_u[a], N[kids[k]].aabb_min[a]);
+        hi_u[a] = std::fmax(hi_u[a], N[kids[k]].aabb_max[a]);
+      }
+      r.origin[a] = lo_u[a];
+    }
+    uint32_t q_lo[3][4] = {}, q_hi[3][4] = {};
+    for (int a = 0; a < 3; ++a) {
+      int e2 = 0;
+      const float ext = hi_u[a] - lo_u[a];
+      (void)std::frexp(ext > 0.0f ? ext / 255.0f : 0.0f, &e2);  // ext / 255 < 2^e2
+      int E = ext > 0.0f ? e2 + 127 : 1;
+      if (E < 1) E = 1;
+      for (;; ++E) {  // the smallest cell that covers the extent with 255 steps, outward rounding included
+        if (E > 254) E = 254;
+        const float cell = std::ldexp(1.0f, E - 127);
+        bool ok = true;
+        for (uint32_t k = 0; k < nk && ok; ++k) {
+          const float lo = N[kids[k]].aabb_min[a], hi = N[kids[k]].aabb_max[a];
+          double ql = std::floor((static_cast<double>(lo) - lo_u[a]) / cell), qh = std::ceil((static_cast<double>(hi) - lo_u[a]) / cell);
+          if (ql < 0.0) ql = 0.0;
+          if (ql > 255.0) ql = 255.0;
+          while (ql > 0.0 && lo_u[a] + static_cast<float>(ql) * cell > lo) ql -= 1.0;
+          if (qh < 0.0) qh = 0.0;
+          while (qh <= 255.0 && lo_u[a] + static_cast<float>(qh) * cell < hi) qh += 1.0;
+          if (qh > 255.0) ok = false;
+          q_lo[a][k] = static_cast<uint32_t>(ql);
+          q_hi[a][k] = static_cast<uint32_t>(qh);
+        }
+        if (ok || E == 254) break;
+      }
+      r.exps |= static_cast<uint32_t>(E) << (8 * a);
+    }
+    std::array<uint32_t, 4> kw{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    for (uint32_t k = 0; k < 4; ++k) {
+      if (k >= nk) {  // an empty place: an inverted box and an entry the walk never follows
+        r.entry[k] = 0xFFFFFFFFu;
+        for (int a = 0; a < 3; ++a) q_lo[a][k] = 255u, q_hi[a][k] = 0u;
+        continue;
+      }
+      const pt_packed_bvh_node& c = N[kids[k]];
+      if (c.triangle_count == 0) {
+        kw[k] = static_cast<uint32_t>(order.size());
+        r.entry[k] = kw[k] << 7;
+        order.push_back(kids[k]);
+      } else {
+        r.entry[k] = (c.left_or_begin << 7) | c.triangle_count;
+      }
+    }
+    for (uint32_t k = 0; k < 4; ++k) {
+      r.lo[0] |= q_lo[0][k] << (8 * k);
+      r.lo[1] |= q_lo[1][k] << (8 * k);
+      r.lo[2] |= q_lo[2][k] << (8 * k);
+      r.hi_x |= q_hi[0][k] << (8 * k);
+      r.hi_y |= q_hi[1][k] << (8 * k);
+      r.hi_z |= q_hi[2][k] << (8 * k);
+    }
+    rec.push_back(r);
+    kid_wide.push_back(kw);
+    kid_count.push_back(nk);
+  }
+  // deferred children a walk may hold at once: entering one child of a record leaves up to (children - 1) on the stack
+  std::vector<uint32_t> need(rec.size(), 0);
+  for (size_t w = rec.size(); w-- > 0;) {
+    uint32_t below = 0;
+    for (uint32_t k = 0; k < 4; ++k)
+      if (kid_wide[w][k] != 0xFFFFFFFFu && need[kid_wide[w][k]] > below) below = need[kid_wide[w][k]];
+    need[w] = kid_count[w] - 1u + below;
+  }
+  stack_need = need.empty() ? 0u : need[0];
+}
+
+}  // namespace
 
 static int upload_one(pt_ctx* ctx, const pt_scene_desc* s) {
   PT_HIP(ctx, hipSetDevice(ctx->device));
@@ -726,6 +848,15 @@ static int upload_one(pt_ctx* ctx, const pt_scene_desc* s) {
                     ctx->lds_scene_bytes &&
                     d.pair_count < 65536u && s->triangle_count < 65536u)  // LDS stack entries pack (ref << 16 | cnt)
                        ? 1u : 0u;
+  if (ctx->wide4 && !d.scene_in_lds && d.packed_stack) {  // PT_BVH=wide4 (opt-in): the collapsed tree beside the reference's
+    std::vector<WideRecord> wide;
+    build_wide(s, wide, d.wide_stack_need);
+    d.wide_count = static_cast<uint32_t>(wide.size());
+    if (d.wide_count && d.wide_count < (1u << 25)) {
+      if ((rc = dev_upload(ctx, ctx->scene_bufs, &d.wide, reinterpret_cast<const float4*>(wide.data()), 4 * wide.size())) != PT_OK) return rc;
+      PT_HIP(ctx, hipStreamSynchronize(ctx->stream));  // wide dies here
+    }
+  }
   PT_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
   PT_HIP(ctx, hipStreamSynchronize(ctx->stream));  // host staging vectors die here
   float ms = 0.0f;
@@ -812,6 +943,11 @@ int render_accum_impl(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev,
   const auto launch_extend = rs ? ptd_rs::launch_extend : ptd::launch_extend;
   const auto launch_shade = rs ? ptd_rs::launch_shade : ptd::launch_shade;
   const auto launch_shadow = rs ? ptd_rs::launch_shadow : ptd::launch_shadow;
+  // PT_BVH=wide4: only k_paths_merged of the exact compilation walks the wide records, and only if the lane's LDS rows plus its 128
+  // private rows hold the worst-case number of deferred children; everything else walks the reference's tree.
+  if (sc.wide && !(merged && !rs && !ctx->fast_arith &&
+                   sc.wide_stack_need + 1u <= (sc.lds_stack_levels ? sc.lds_stack_levels : sc.stack_entries) + 128u))
+    sc.wide = nullptr;
   const auto launch_paths_exact = rs ? ptd_rs::launch_paths : ptd::launch_paths;
   const auto launch_paths = merged ? ((ctx->fast_arith && !rs) ? ptd_fast::launch_paths_merged : (rs ? ptd_rs::launch_paths_merged : ptd::launch_paths_merged))
                                    : ((ctx->fast_arith && !rs) ? ptd_fast::launch_paths : launch_paths_exact);  // the fast build has packed entries only
@@ -1081,6 +1217,7 @@ int render_accum_impl(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev,
     stats_out->iterations = iter;
     stats_out->scene_in_lds = sc.scene_in_lds;
     stats_out->merged_walk = merged ? 1u : 0u;
+    stats_out->bvh_wide4 = sc.wide ? 1u : 0u;
     pt_kernel_stats* per[PT_K_COUNT + 1] = {nullptr, &stats_out->extend, &stats_out->shade, &stats_out->shadow, &stats_out->path_kernel};
     stats_out->path_kernel.launches = launches[PT_K_PATHS];
     for (int k = PT_K_EXTEND; k < PT_K_COUNT; ++k) {

@@ -31,6 +31,7 @@ enum { PT_K_INIT = 0, PT_K_EXTEND, PT_K_SHADE, PT_K_SHADOW, PT_K_COUNT, PT_K_PAT
 //   materials  shade             — the reference's 64-byte Material array verbatim
 struct pt_dev_scene {
   const float4* pairs;
+  const float4* wide;                // PT_BVH=wide4 (opt-in): 64-byte records of up to four children with 8-bit boxes (pt_kernels.hip); NULL otherwise
   const float4* tri_pos;
   const float4* tri_attr;
   const float4* materials;
@@ -46,6 +47,8 @@ struct pt_dev_scene {
   uint32_t material_count;
   uint32_t emissive_count;
   uint32_t pair_count;
+  uint32_t wide_count;               // wide records
+  uint32_t wide_stack_need;          // deferred children a wide walk may hold at once (worst case over the tree)
   uint32_t root_ref, root_cnt;       // the root as a child reference: pair 0 (count 0) or a leaf's triangle range
   uint32_t scene_in_lds;             // 1: the scene (pair records, triangle positions; for shading also attributes, materials, lights, emitter list) is staged whole in the workgroup's LDS
   uint32_t all_opaque;               // 1: no surface can report alpha != 1 (shadow rays may stop at the first hit)

@@ -226,13 +226,14 @@ __device__ __forceinline__ void ray_box_pair(vec3 o, vec3 inv, const float4& q0,
 // fetches are global loads (L1/L2/Infinity Cache/HBM).
 struct Tracer {
   const float4* pairs;    // LDS or global, breadth-first
+  const float4* wide;     // PT_BVH=wide4 (opt-in, global memory): 64-byte records of up to four children with 8-bit boxes; else NULL
   const float4* tri_pos;  // LDS or global, 3 x float4 per triangle
   uint32_t root_ref, root_cnt;
   uint32_t stack;         // LDS byte address of this lane's column of the traversal stack
   uint32_t stride;        // bytes from one level to the next
   uint32_t stack_end;     // scenes in global memory: LDS byte address one past this lane's last LDS row; pushes beyond it go to private memory
 #ifdef PT_GUARD
-  uint32_t g_pairs, g_tris;
+  uint32_t g_pairs, g_tris, g_wide;
 #endif
 };
 
@@ -441,7 +442,9 @@ __device__ __forceinline__ void traverse(const Tracer& tr, vec3 o, vec3 d, Hit& 
     bool hit_l, hit_r;
     ray_box_pair(o, inv, q0, q1, q2, h.t, hit_l, hit_r, dist_l, dist_r, exit_l, exit_r);
     if (hit_l || hit_r) {
-      const bool go_left = hit_l && (!hit_r || left_first<false>(dist_l, dist_r, exit_l, exit_r));  // equal distances: right is near (Q14); LDS scenes: any-hit walks too
+      // (the comparison written here, not behind left_first<false>: as a call hipcc materialised the bools with v_cndmask / v_cmp, five more
+      // VALU instructions per inner trip, cfg2 -1.9 %)
+      const bool go_left = hit_l && (!hit_r || dist_l < dist_r);  // equal distances: right is near (Q14); LDS scenes: any-hit walks too
       if (hit_l && hit_r) {
         // the far side: the child itself for LDS scenes (a pop then needs no fetch: +0.4 % on cfg2), else (record, side)
         if (IN_LDS) stack_store(sp, go_left ? (fbits(q3.z) << 16) | fbits(q3.w) : (fbits(q3.x) << 16) | fbits(q3.y));
@@ -507,7 +510,9 @@ __device__ __forceinline__ void traverse(const Tracer& tr, vec3 o, vec3 d, Hit& 
         bool hit_l, hit_r;
         ray_box_pair(o, inv, q0, q1, q2, h.t, hit_l, hit_r, dist_l, dist_r, exit_l, exit_r);
         if (hit_l || hit_r) {
-          const bool go_left = hit_l && (!hit_r || left_first<ANY_HIT>(dist_l, dist_r, exit_l, exit_r));
+          bool go_left;
+          if constexpr (ANY_HIT) go_left = hit_l && (!hit_r || left_first<true>(dist_l, dist_r, exit_l, exit_r));
+          else go_left = hit_l && (!hit_r || dist_l < dist_r);
           if (hit_l && hit_r) {
 #if PT_STACK_CHILD  // the far side: the child itself, or (record, side)
             const uint32_t e = ((go_left ? fbits(q3.z) : fbits(q3.x)) << 7) | (go_left ? fbits(q3.w) : fbits(q3.y));
@@ -552,6 +557,7 @@ template <bool IN_LDS>
 __device__ __forceinline__ Tracer make_tracer(const pt_dev_scene& sc, uint32_t* lds) {
   Tracer tr;
   tr.pairs = sc.pairs;
+  tr.wide = sc.wide;
   tr.tri_pos = sc.tri_pos;
   if (IN_LDS) {
     float4* lds_pair = reinterpret_cast<float4*>(lds + static_cast<size_t>(blockDim.x) * sc.stack_entries);
@@ -570,6 +576,7 @@ __device__ __forceinline__ Tracer make_tracer(const pt_dev_scene& sc, uint32_t* 
 #ifdef PT_GUARD
   tr.g_pairs = sc.pair_count;
   tr.g_tris = sc.triangle_count;
+  tr.g_wide = sc.wide_count;
 #endif
   if (!IN_LDS) tr.stack_end = tr.stack + (sc.lds_stack_levels ? sc.lds_stack_levels : sc.stack_entries) * tr.stride;
   return tr;
@@ -694,8 +701,11 @@ __device__ __forceinline__ int wrap_coord(int i, int n, uint32_t mode) {
 
 __device__ __forceinline__ float4 texel(const uint32_t* __restrict__ texels, uint32_t base, int w, int x, int y) {
   const uint32_t p = texels[base + static_cast<uint32_t>(y) * static_cast<uint32_t>(w) + static_cast<uint32_t>(x)];
-  return make_float4(sdiv(static_cast<float>(p & 255u), 255.0f), sdiv(static_cast<float>((p >> 8) & 255u), 255.0f),
-                     sdiv(static_cast<float>((p >> 16) & 255u), 255.0f), sdiv(static_cast<float>(p >> 24), 255.0f));
+  // UNORM decode with the IEEE divide in BOTH builds: main.comp branches on alpha == 1.0 / alpha < 1.0 (:325, :542), and with the fast
+  // build's x * rcp(255) a 255 byte came out as 0.99999994 — every textured wall a pass-through surface (cfg3: relMSE 0.039, found by
+  // bench.py's fast_arith leg once the headline moved there)
+  return make_float4(static_cast<float>(p & 255u) / 255.0f, static_cast<float>((p >> 8) & 255u) / 255.0f,
+                     static_cast<float>((p >> 16) & 255u) / 255.0f, static_cast<float>(p >> 24) / 255.0f);
 }
 
 // sample_texture, main.comp:221-224
@@ -1472,7 +1482,9 @@ __global__ __launch_bounds__(256, ALL_OPAQUE ? PT_SHADOW_MIN_WAVES_OPAQUE : PT_S
   const uint32_t n_lights = sc.directional_light_count + sc.point_light_count + (f.pc.emissive_triangle_count ? 1u : 0u);
   const vec3 bg_linear = mk(f.bg_linear[0], f.bg_linear[1], f.bg_linear[2]);
   const size_t ss = st.slot_stride;
-  if (blockIdx.x * blockDim.x < n) {  // block-uniform
+  // (n_lights != 0 tested HERE, with the scalar unit: the host only launches this kernel for scenes with lights, and left to the light
+  // loop's own guard the compiler turned the wave-uniform comparison into a lane mask in the prologue — scripts/check_isa.py's pattern)
+  if (blockIdx.x * blockDim.x < n && n_lights != 0u) {  // block-uniform
     const Tracer tr = make_tracer<false>(sc, lds_dyn);
     const ShadeData sd = make_shade_data<false>(sc, tr, lds_dyn);
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
@@ -1583,7 +1595,49 @@ __device__ __forceinline__ vec3 cold_get(volatile float* cold, uint32_t at) {
   return mk(x, y, z);
 }
 
-template <bool ALL_OPAQUE, bool TEXTURED>
+// ---- PT_BVH=wide4 (opt-in; NOT bit-exact: validated by north_star's tolerance like PT_ARITH=fast) ---------------------------------
+// The walk is bound by the number of divergent 16-byte lane loads, four per inner-node visit. A wide record puts up
+// to FOUR children into the same 64 bytes (built at upload by collapsing the reference's binary tree, pt_context.hip): a common
+// origin and per-axis power-of-two scale, 8-bit child boxes rounded outwards, four child entries (ref << 7 | cnt) — half the visits
+// per ray, so half the loads, and a third of the node bytes. The boxes are supersets of the reference's and the children are
+// entered nearest first, so the closest hit is the reference's except where two candidates tie exactly or a ray grazes a box the
+// reference's slab test misses by a rounding; any-hit walks take the children in record order.
+// Record: {origin.xyz, ex | ey << 8 | ez << 16 (biased exponents)} {entry 0..3} {lo.x[4], lo.y[4], lo.z[4], hi.x[4]} {hi.y[4], hi.z[4], -, -}.
+constexpr uint32_t kDeepLevelsWide = 128;  // a wide visit defers up to three children
+struct WideHits {
+  float key[4];      // entry distance of child c if the ray enters its box before the closest hit so far, else +inf
+  uint32_t entry[4];
+};
+__device__ __forceinline__ float ubyte_f(uint32_t w, uint32_t c) { return static_cast<float>((w >> (8u * c)) & 255u); }  // v_cvt_f32_ubyteN
+__device__ __forceinline__ WideHits wide_visit(vec3 o, vec3 inv, const float4& q0, const float4& q1, const float4& q2, const float4& q3, float t_best) {
+  const uint32_t ex = fbits(q0.w);
+  const vec3 scale = mk(ubits((ex & 255u) << 23), ubits(((ex >> 8) & 255u) << 23), ubits(((ex >> 16) & 255u) << 23));
+  const vec3 a = mk(scale.x * inv.x, scale.y * inv.y, scale.z * inv.z);
+  const vec3 b = mk((q0.x - o.x) * inv.x, (q0.y - o.y) * inv.y, (q0.z - o.z) * inv.z);
+  const uint32_t lox = fbits(q2.x), loy = fbits(q2.y), loz = fbits(q2.z), hix = fbits(q2.w), hiy = fbits(q3.x), hiz = fbits(q3.y);
+  const uint32_t e[4] = {fbits(q1.x), fbits(q1.y), fbits(q1.z), fbits(q1.w)};
+  WideHits r;
+#pragma unroll
+  for (uint32_t c = 0; c < 4u; ++c) {
+    const float x0 = __builtin_fmaf(ubyte_f(lox, c), a.x, b.x), x1 = __builtin_fmaf(ubyte_f(hix, c), a.x, b.x);
+    const float y0 = __builtin_fmaf(ubyte_f(loy, c), a.y, b.y), y1 = __builtin_fmaf(ubyte_f(hiy, c), a.y, b.y);
+    const float z0 = __builtin_fmaf(ubyte_f(loz, c), a.z, b.z), z1 = __builtin_fmaf(ubyte_f(hiz, c), a.z, b.z);
+    const float near = gmax(gmax(gmin(x0, x1), gmin(y0, y1)), gmin(z0, z1));
+    const float far = gmin(gmin(gmax(x0, x1), gmax(y0, y1)), gmax(z0, z1));
+    const bool hit = e[c] != 0xFFFFFFFFu && near <= far && !(far < 0.0f) && near < t_best;
+    r.key[c] = hit ? near : kInfinity * 2.0f;
+    r.entry[c] = e[c];
+  }
+  return r;
+}
+__device__ __forceinline__ void wide_cswap(WideHits& r, int i, int j) {  // key[i] <= key[j] afterwards
+  const bool sw = r.key[j] < r.key[i];
+  const float ki = sw ? r.key[j] : r.key[i], kj = sw ? r.key[i] : r.key[j];
+  const uint32_t ei = sw ? r.entry[j] : r.entry[i], ej = sw ? r.entry[i] : r.entry[j];
+  r.key[i] = ki; r.key[j] = kj; r.entry[i] = ei; r.entry[j] = ej;
+}
+
+template <bool ALL_OPAQUE, bool TEXTURED, bool WIDE = false>
 __device__ __forceinline__ void merged_walk(const pt_dev_scene& sc, const ShadeData& sd, const Tracer& tr, const Stash& stash,
                                             const Pending& pend, bool has_ray, vec3 ray_o, vec3 ray_d, volatile float* cold, Hit& h,
                                             float& vis0, float& vis1, Tally& ext, Tally& walks, Tally& tally) {
@@ -1592,7 +1646,16 @@ __device__ __forceinline__ void merged_walk(const pt_dev_scene& sc, const ShadeD
   vec3 o = splat(0.0f), d = splat(0.0f), inv = splat(0.0f);
   uint32_t sp = tr.stack, ref = 0, cnt = 0, nd = 0;
   bool live = false;
-  uint32_t deep[kDeepLevels];  // rows beyond the lane's LDS rows (private memory), as in traverse()
+  constexpr uint32_t kDeep = WIDE ? kDeepLevelsWide : kDeepLevels;
+  uint32_t deep[kDeep];  // rows beyond the lane's LDS rows (private memory), as in traverse()
+  auto push = [&](uint32_t e) {
+    if (sp != tr.stack_end) {
+      stack_store(sp, e);
+      sp += tr.stride;
+    } else {
+      deep[nd++] = e;
+    }
+  };
   auto start = [&]() {         // the lane's next job (lowest bit of todo)
     cur = todo & (0u - todo);
     todo ^= cur;
@@ -1620,7 +1683,7 @@ __device__ __forceinline__ void merged_walk(const pt_dev_scene& sc, const ShadeD
       const bool any_hit = ALL_OPAQUE && cur != 4u;
       bool need_pop = true;
 #ifdef PT_GUARD
-      if ((cnt > 0 ? (ref + cnt > tr.g_tris) : (ref >= tr.g_pairs)) || nd > kDeepLevels || sp < tr.stack || sp > tr.stack_end) {
+      if ((cnt > 0 ? (ref + cnt > tr.g_tris) : (ref >= (WIDE ? tr.g_wide : tr.g_pairs))) || nd + (WIDE ? 3u : 0u) > kDeep || sp < tr.stack || sp > tr.stack_end) {
         printf("[guard] merged walk: ref %u cnt %u nd %u sp %u job %u (block %u thread %u)\n", ref, cnt, nd, sp, cur, blockIdx.x, threadIdx.x);
         live = false;
         need_pop = false;
@@ -1642,6 +1705,24 @@ __device__ __forceinline__ void merged_walk(const pt_dev_scene& sc, const ShadeD
           ext.tests += cnt;
           for (uint32_t i = 0; i < cnt; ++i) ray_triangle<false, true>(tr, o, d, ref + i, h);
         }
+      } else if constexpr (WIDE && PT_STACK_CHILD != 0) {
+        ++ext.visits;
+        float4 q0, q1, q2, q3;
+        fetch16x4<false, true>(tr.wide, 4 * ref, q0, q1, q2, q3);
+        WideHits w = wide_visit(o, inv, q0, q1, q2, q3, h.t);
+        wide_cswap(w, 0, 1);  // nearest child first (sorting network), the others deferred farthest first
+        wide_cswap(w, 2, 3);
+        wide_cswap(w, 0, 2);
+        wide_cswap(w, 1, 3);
+        wide_cswap(w, 1, 2);
+        if (w.key[0] < kInfinity * 2.0f) {
+          if (w.key[3] < kInfinity * 2.0f) push(w.entry[3]);
+          if (w.key[2] < kInfinity * 2.0f) push(w.entry[2]);
+          if (w.key[1] < kInfinity * 2.0f) push(w.entry[1]);
+          ref = w.entry[0] >> 7;
+          cnt = w.entry[0] & 127u;
+          need_pop = false;
+        }
       } else {
         ++ext.visits;
         // (the four quads as four 128-bit values: read as one 64-byte vector, the register allocator kept the record as ONE 16-register
@@ -1652,21 +1733,16 @@ __device__ __forceinline__ void merged_walk(const pt_dev_scene& sc, const ShadeD
         bool hit_l, hit_r;
         ray_box_pair(o, inv, q0, q1, q2, h.t, hit_l, hit_r, dist_l, dist_r, exit_l, exit_r);
         if (hit_l || hit_r) {
-          const bool first_l = ALL_OPAQUE ? (any_hit ? left_first<true>(dist_l, dist_r, exit_l, exit_r) : left_first<false>(dist_l, dist_r, exit_l, exit_r))
-                                          : left_first<false>(dist_l, dist_r, exit_l, exit_r);
-          const bool go_left = hit_l && (!hit_r || first_l);
+          bool go_left;
+          if constexpr (ALL_OPAQUE) go_left = hit_l && (!hit_r || (any_hit ? left_first<true>(dist_l, dist_r, exit_l, exit_r) : dist_l < dist_r));
+          else go_left = hit_l && (!hit_r || dist_l < dist_r);
           if (hit_l && hit_r) {
 #if PT_STACK_CHILD  // the far side: the child itself, or (record, side)
             const uint32_t e = ((go_left ? fbits(q3.z) : fbits(q3.x)) << 7) | (go_left ? fbits(q3.w) : fbits(q3.y));
 #else
             const uint32_t e = (ref << 1) | (go_left ? 1u : 0u);
 #endif
-            if (sp != tr.stack_end) {
-              stack_store(sp, e);
-              sp += tr.stride;
-            } else {
-              deep[nd++] = e;
-            }
+            push(e);
           }
           ref = go_left ? fbits(q3.x) : fbits(q3.z);
           cnt = go_left ? fbits(q3.y) : fbits(q3.w);
@@ -1870,7 +1946,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_paths(pt_dev_scene sc, pt_de
 // k_paths for scenes read from global memory with at most two light samples per vertex: same state, same queues, same per-slot
 // order of work, but a vertex's shadow walks ride with the next vertex's closest-hit walk in one loop (merged_walk). The last
 // vertex a slot shades in a launch leaves light samples behind: one more round walks those alone, so nothing pends across launches.
-template <bool ALL_OPAQUE, int MIN_WAVES, bool TEXTURED>
+template <bool ALL_OPAQUE, int MIN_WAVES, bool TEXTURED, bool WIDE = false>
 __global__ __launch_bounds__(256, MIN_WAVES) void k_paths_merged(pt_dev_scene sc, pt_dev_frame f, pt_dev_state st, uint32_t parity,
                                                                           uint32_t cnt_in, uint32_t cnt_out, uint32_t cnt_zero,
                                                                           uint32_t max_vertices, uint32_t xcd_chunk) {
@@ -1927,7 +2003,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_paths_merged(pt_dev_scene sc
           cold_put(cold, COLD_RAY_D, d);
 #endif
           Hit h{kInfinity, 0.0f, 0.0f, kNoHit};
-          merged_walk<ALL_OPAQUE, TEXTURED>(sc, sd, tr, stash, pend, has_ray, o, d, cold, h, vis0, vis1, ext, walks, tally);
+          merged_walk<ALL_OPAQUE, TEXTURED, WIDE>(sc, sd, tr, stash, pend, has_ray, o, d, cold, h, vis0, vis1, ext, walks, tally);
 #if PT_MERGED_COLD
           // ... and take it back
           p.indirect = cold_get(cold, COLD_INDIRECT);
@@ -2161,8 +2237,16 @@ void launch_paths_merged(const pt_dev_scene& sc, const pt_dev_frame& f, const pt
   }
   const size_t lds = merged_lds_bytes(sc, block);
   const bool textured = sc.any_texture != 0;
+#if PT_STACK_CHILD && !defined(PT_FAST_ARITH)  // the wide4 walk exists in the exact compilation only (its entries are packed children)
+#define PT_LAUNCH_MERGED(B, W, T)                                                                                                                \
+  do {                                                                                                                                           \
+    if (sc.wide) hipLaunchKernelGGL((k_paths_merged<B, W, T, true>), dim3(grid), dim3(block), lds, s, sc, f, st, parity, cnt_in, cnt_out, cnt_zero, max_vertices, xcd_chunk); \
+    else hipLaunchKernelGGL((k_paths_merged<B, W, T, false>), dim3(grid), dim3(block), lds, s, sc, f, st, parity, cnt_in, cnt_out, cnt_zero, max_vertices, xcd_chunk);        \
+  } while (0)
+#else
 #define PT_LAUNCH_MERGED(B, W, T) \
   hipLaunchKernelGGL((k_paths_merged<B, W, T>), dim3(grid), dim3(block), lds, s, sc, f, st, parity, cnt_in, cnt_out, cnt_zero, max_vertices, xcd_chunk)
+#endif
 #define PT_LAUNCH_MERGED_BY_SIZE(B)                                      \
   do {                                                                   \
     if (textured) PT_LAUNCH_MERGED(B, PT_MERGED_MIN_WAVES, true);        \

@@ -1,0 +1,19 @@
+#!/bin/bash
+# the driver's command, as the driver runs it
+set -u
+mkdir -p gpurun_out
+timeout -k 10 900 python3 -u bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r03_bench.json 2> gpurun_out/r03_bench.err || { echo "bench failed"; tail -20 gpurun_out/r03_bench.err; exit 1; }
+tail -25 gpurun_out/r03_bench.err
+python3 - <<'PY'
+import json
+d = json.load(open("gpurun_out/r03_bench.json"))
+def show(c):
+    r = c.get("roofline", {})
+    print(c.get("name", c["config"]["name"]), f"{c['value']:.0f} Mrays/s {c['ms_per_step']:.1f} ms", "verified", c.get("frame_verified"), "props", c.get("frame_properties_ok"),
+          "band", c.get("cpu_baseline", {}).get("gpu_band_bit_exact"), "roof", r.get("bound"), f"{r.get('frac', 0):.3f}", r.get("kernel"), "cpu", f"{c.get('cpu_baseline', {}).get('value', 0):.1f}")
+show(d)
+for c in d.get("configs", []):
+    if "skipped" in c: print(c)
+    else: show(c)
+print("fast", d.get("fast_arith"))
+PY
