@@ -57,6 +57,7 @@ WORKLOADS = {
 }
 BG = {"atrium1080": (0.5, 0.7, 1.0), "rocks1080": (0.5, 0.7, 1.0), "soup1080": (0.5, 0.7, 1.0)}  # sky; others: README default
 HEADLINE = "atrium1080"
+FAST_ARITH_WORKLOAD = "cornell1080"  # cfg2: the LDS-resident scene PT_ARITH=fast is for
 EXTRA_DEFAULT = "cornell1080,cube512,atrium1080,rocks1080,cornell4k"  # (the headline workload is skipped in this list)
 EXTRA_STEPS = {"cornell1080": 20, "cube512": 20, "atrium1080": 2, "rocks1080": 2, "cornell4k": 1}
 SEED = 0x5EED0000
@@ -309,7 +310,7 @@ def cpu_baseline(packed, rp, gpu_accum, gpu_ids, seconds_hint: float) -> dict:
 # --------------------------------------------------------------------------- one workload
 
 def run_workload(be, name: str, steps: int, warmup: int, world: int, rank: int, split: str, spp_override: int,
-                 kernel_timing: bool, baseline_seconds: float, dist, collectives: bool | None = None) -> dict | None:
+                 kernel_timing: bool, baseline_seconds: float, dist, collectives: bool | None = None, want_noise: bool = False) -> dict | None:
     """Render `name` steps times on every rank; returns rank 0's result dict (None elsewhere).  `collectives`: run the
     reduce / barrier / all-reduce legs (default: whenever world > 1; a one-GPU box forces them on a one-rank group to
     exercise the RCCL path, PT_BENCH_FORCE_COLLECTIVES=1)."""
@@ -453,6 +454,12 @@ def run_workload(be, name: str, steps: int, warmup: int, world: int, rank: int, 
     if frame is not None:
         accum, ids, rgba = frame
         out["_frame"] = frame
+        if want_noise:
+            # The same frame from ANOTHER seed: the Monte-Carlo noise between two sample sets at this sample count, i.e. what a per-pixel
+            # relMSE between the exact build and an opt-in build (whose paths decorrelate at the first grazing ray, Q2) can be held against.
+            rp2 = packed.render_params(be.lib, width, height, spp, bg, SEED + 1)
+            be.render(rp2, None, False)
+            out["_noise"] = rel_mse(be.host_frame()[0], accum)
         gold_file = os.path.join(ROOT, "tests", "golden", f"{name}_full_digest.json")
         if name == "cornell1080":
             gold_file = os.path.join(ROOT, "tests", "golden", "cfg2_full_digest.json")
@@ -495,17 +502,28 @@ def rel_mse(a, b, eps: float = 1e-2) -> float:
     return float(np.mean((a - b) ** 2 / (b * b + eps)))
 
 
-def fast_arith_leg(name: str, steps: int, exact_frame, exact_value: float) -> dict:
-    """The same workload on the opt-in fast-arithmetic build of the path kernel (PT_ARITH=fast: hardware rcp / sqrt / rsq /
-    exp2 / log2 / sin / cos and FMA contraction in the shading half), timed the same way and compared with the exact
-    frame by north_star's tolerance (relMSE <= 1e-3, primary-hit ids >= 99.99 %): what the bit-exact contract costs."""
+def block_sums(accum, width: int, height: int, n: int = 16):
+    """Accumulator frame [H*W, 4] summed over n x n pixel blocks (ragged edges dropped): the same estimator at 1 / n^2 of the variance."""
+    h, w = height // n * n, width // n * n
+    return accum.reshape(height, width, 4)[:h, :w].reshape(h // n, n, w // n, n, 4).sum(axis=(1, 3)).reshape(-1, 4)
+
+
+def optin_leg(name: str, steps: int, exact_frame, exact_value: float, env: dict, note: str, noise: float | None) -> dict:
+    """The same workload on an OPT-IN build that is not bit-exact by design, timed the same way and compared with the exact frame by
+    north_star's tolerance (relMSE <= 1e-3, primary-hit ids >= 99.99 %) — what the bit-exact contract costs:
+      PT_ARITH=fast  the path kernel with hardware rcp / sqrt / rsq / exp2 / log2 / sin / cos and FMA contraction in the shading half;
+      PT_BVH=wide4   64-byte records of up to four children with 8-bit boxes instead of the reference's binary tree.
+    In an open scene one grazing ray that hits in one build and escapes in the other shifts the pixel's RNG stream (Q2) and decorrelates
+    the rest of its samples, so per pixel the frames differ by Monte-Carlo noise (`relmse_noise_other_seed`: the exact build against
+    itself from another seed); the tolerance applies where that noise is averaged out (`relmse_block16_vs_exact`)."""
     import numpy as np
     from pathtracer_amd import abi, scenes
-    os.environ["PT_ARITH"] = "fast"
+    os.environ.update(env)
     try:
-        be = HipBackend(int(os.environ.get("LOCAL_RANK", "0")))  # the context reads PT_ARITH at creation
+        be = HipBackend(int(os.environ.get("LOCAL_RANK", "0")))  # the context reads its knobs at creation
     finally:
-        del os.environ["PT_ARITH"]
+        for k in env:
+            del os.environ[k]
     factory, kwargs, width, height, spp, _ = WORKLOADS[name]
     packed = be.pack(getattr(scenes, factory)(**kwargs))
     be.upload(packed)
@@ -529,10 +547,14 @@ def fast_arith_leg(name: str, steps: int, exact_frame, exact_value: float) -> di
     be.close()
     e_accum, e_ids, _ = exact_frame
     value = rays / elapsed / 1e6
-    return {"value": value, "unit": "Mrays/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
-            "speedup_over_exact": value / exact_value, "relmse_vs_exact": rel_mse(accum, e_accum), "relmse_tolerance": 1e-3,
+    return {"workload": name, "value": value, "unit": "Mrays/s", "ms_per_step": 1e3 * elapsed / steps, "steps": steps,
+            "speedup_over_exact": value / exact_value, "relmse_vs_exact": rel_mse(accum, e_accum),
+            "relmse_block16_vs_exact": rel_mse(block_sums(accum, width, height), block_sums(e_accum, width, height)),
+            "relmse_noise_other_seed": noise, "relmse_tolerance": 1e-3,
             "primary_id_agreement": float((ids == e_ids).mean()), "nan_samples": int(stats.nan_samples),
-            "note": "opt-in build (PT_ARITH=fast); the headline value above is the exact build, which is bit-identical to the oracle"}
+            "node_visits": int(stats.node_visits), "rays": int(stats.rays),
+            "in_effect": {"fast_arith": int(stats.fast_arith), "bvh_wide4": int(stats.bvh_wide4), "merged_walk": int(stats.merged_walk)},
+            "note": note + "; the headline value above is the exact build, which is bit-identical to the oracle"}
 
 
 def main(argv=None, backend_factory=None) -> None:
@@ -549,7 +571,7 @@ def main(argv=None, backend_factory=None) -> None:
     ap.add_argument("--spp", type=int, default=0, help="override sample_count (dev only; invalidates the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="skip the extra profiled step that feeds `roofline`")
-    ap.add_argument("--no-fast-arith", action="store_true", help="skip the PT_ARITH=fast comparison leg (N = 1 only)")
+    ap.add_argument("--no-fast-arith", action="store_true", help="skip the opt-in comparison legs (PT_ARITH=fast, PT_BVH=wide4; N = 1 only)")
     ap.add_argument("--time-budget-s", type=float, default=420.0, help="extra configs are skipped once the run is this old")
     args = ap.parse_args(argv)
 
@@ -572,15 +594,16 @@ def main(argv=None, backend_factory=None) -> None:
         kw = {"device_id": be.dev} if be.dist_backend == "nccl" else {}
         dist.init_process_group(be.dist_backend, rank=rank, world_size=world, **kw)
 
+    optin = (world == 1 and not args.no_fast_arith and backend_factory is None and not args.spp
+             and os.environ.get("PT_ARITH") != "fast" and os.environ.get("PT_BVH") != "wide4")
     head = run_workload(be, args.workload, args.steps, args.warmup, world, rank, args.split, args.spp,
-                        not args.no_kernel_timing, 0.0 if args.no_cpu_baseline else 12.0, dist, collectives)
-    fast = None
-    if (world == 1 and head is not None and "_frame" in head and not args.no_fast_arith and backend_factory is None
-            and not args.spp and os.environ.get("PT_ARITH") != "fast"):
-        progress(f"{args.workload}: the fast-arithmetic build")
-        fast = fast_arith_leg(args.workload, args.steps, head["_frame"], head["value"])
-    if head is not None:
-        head.pop("_frame", None)
+                        not args.no_kernel_timing, 0.0 if args.no_cpu_baseline else 12.0, dist, collectives, want_noise=optin)
+    fast = wide = None
+    if optin and head is not None and "_frame" in head:
+        progress(f"{args.workload}: the opt-in tree (PT_BVH=wide4)")
+        wide = optin_leg(args.workload, args.steps, head["_frame"], head["value"], {"PT_BVH": "wide4"},
+                         "opt-in tree (PT_BVH=wide4: scenes read from global memory with at most two light samples per vertex; elsewhere it is the default walk)",
+                         head.get("_noise"))
     extras = []
     if world == 1 and args.configs != "none":
         for name in [c for c in args.configs.split(",") if c and c != args.workload]:
@@ -590,6 +613,18 @@ def main(argv=None, backend_factory=None) -> None:
             extras.append(run_workload(be, name, EXTRA_STEPS.get(name, 2), 0, 1, 0, "replicate", 0, not args.no_kernel_timing,
                                        0.0 if args.no_cpu_baseline else 4.0, dist))
 
+    # PT_ARITH=fast applies to scenes staged in LDS (pt_render runs the exact kernels on scenes read from global memory, where the
+    # fast compilation measured slower): its leg is timed on cfg2, against the exact cfg2 frame of the list above.
+    cfg2 = next((e for e in extras + [head] if e and e.get("name") == FAST_ARITH_WORKLOAD and "_frame" in e), None)
+    if optin and cfg2 is not None:
+        progress(f"{FAST_ARITH_WORKLOAD}: the opt-in build (PT_ARITH=fast)")
+        fast = optin_leg(FAST_ARITH_WORKLOAD, 8, cfg2["_frame"], cfg2["value"], {"PT_ARITH": "fast"},
+                         "opt-in build (PT_ARITH=fast: scenes staged in LDS only; scenes read from global memory, the headline among them, run the exact kernels whatever PT_ARITH says)",
+                         None)
+
+    if head is not None:
+        head.pop("_frame", None)
+        head.pop("_noise", None)
     if rank == 0:
         cfg = dict(head["config"])
         cfg["parallelism"] = (f"dp{world}, {args.split}: " +
@@ -609,6 +644,8 @@ def main(argv=None, backend_factory=None) -> None:
                 out[k] = head[k]
         if fast:
             out["fast_arith"] = fast
+        if wide:
+            out["bvh_wide4"] = wide
         for e in extras:
             if e:
                 e.pop("_frame", None)

@@ -237,6 +237,8 @@ typedef struct pt_stats {
                                     work is then counted in the `extend` slice                                   */
   uint64_t bvh_wide4;            /* 1: PT_BVH=wide4 was in effect (opt-in, NOT bit-exact): node_visits counts visits of
                                     64-byte records of up to four children with 8-bit boxes                       */
+  uint64_t fast_arith;           /* 1: PT_ARITH=fast was in effect (opt-in, NOT bit-exact; scenes staged in LDS only: scenes read
+                                    from global memory wait on memory and run the exact kernels whatever PT_ARITH says) */
 } pt_stats;
 
 #define PT_FLAG_TIME_KERNELS 1u /* bracket every kernel with HIP events (serialises; for profiling) */
@@ -365,6 +367,16 @@ PT_API int pt_make_push_constants(const pt_render_config* config, const pt_camer
  * so a baseline run can state the reference's launch shape; the HIP path does not use it. */
 PT_API void pt_reference_work_group_size(uint32_t resolution_x, uint32_t resolution_y,
                                          uint32_t* local_x, uint32_t* local_y);
+
+/* The records PT_BVH=wide4 walks (opt-in; NO COUNTERPART IN THE REFERENCE: a layout derived from its
+ * PackedBVHNode array), built on the host exactly as pt_upload_scene builds them — exported so that the
+ * construction can be checked without a GPU. `nodes` must be a valid tree (children of an inner node at left_or_begin,
+ * left_or_begin + 1; pt_upload_scene validates, this call does not). Each record is 64 bytes:
+ * {origin.xyz, ex | ey << 8 | ez << 16} {entry 0..3 = ref << 7 | cnt, 0xFFFFFFFF = empty} {lo.x[4], lo.y[4], lo.z[4], hi.x[4]}
+ * {hi.y[4], hi.z[4], 0, 0}; child c's box is origin + byte * 2^(e - 127) per axis, rounded outwards. records_out may be NULL to
+ * query the count (at most node_count / 2); *stack_need_out = the most children a walk can have deferred at once. */
+PT_API int pt_build_wide4(const pt_packed_bvh_node* nodes, uint32_t node_count, void* records_out, uint32_t capacity,
+                          uint32_t* record_count_out, uint32_t* stack_need_out);
 
 /* ------------------------------------------------------------------- front end */
 

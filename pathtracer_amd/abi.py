@@ -176,7 +176,7 @@ class Stats(C.Structure):
         ("render_ms", C.c_double), ("upload_ms", C.c_double), ("download_ms", C.c_double),
         ("extend", KernelStats), ("shade", KernelStats), ("shadow", KernelStats), ("path_kernel", KernelStats),
         ("rays_closest", C.c_uint64), ("rays_shadow_walked", C.c_uint64), ("rays_shadow_shortcut", C.c_uint64),
-        ("reduce_ms", C.c_double), ("scene_in_lds", C.c_uint64), ("merged_walk", C.c_uint64), ("bvh_wide4", C.c_uint64),
+        ("reduce_ms", C.c_double), ("scene_in_lds", C.c_uint64), ("merged_walk", C.c_uint64), ("bvh_wide4", C.c_uint64), ("fast_arith", C.c_uint64),
     ]
 
     def as_dict(self) -> dict:

@@ -673,6 +673,24 @@ void build_wide(const pt_scene_desc* s, std::vector<WideRecord>& rec, uint32_t& 
 
 }  // namespace
 
+extern "C" int pt_build_wide4(const pt_packed_bvh_node* nodes, uint32_t node_count, void* records_out, uint32_t capacity,
+                              uint32_t* record_count_out, uint32_t* stack_need_out) {
+  if (!nodes || !node_count || !record_count_out) return PT_ERR_INVALID;
+  pt_scene_desc s{};
+  s.bvh_nodes = nodes;
+  s.bvh_node_count = node_count;
+  std::vector<WideRecord> rec;
+  uint32_t need = 0;
+  build_wide(&s, rec, need);
+  *record_count_out = static_cast<uint32_t>(rec.size());
+  if (stack_need_out) *stack_need_out = need;
+  if (records_out) {
+    if (rec.size() > capacity) return PT_ERR_LIMIT;
+    std::memcpy(records_out, rec.data(), rec.size() * sizeof(WideRecord));
+  }
+  return PT_OK;
+}
+
 static int upload_one(pt_ctx* ctx, const pt_scene_desc* s) {
   PT_HIP(ctx, hipSetDevice(ctx->device));
   uint32_t depth = 0;
@@ -945,12 +963,16 @@ int render_accum_impl(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev,
   const auto launch_shadow = rs ? ptd_rs::launch_shadow : ptd::launch_shadow;
   // PT_BVH=wide4: only k_paths_merged of the exact compilation walks the wide records, and only if the lane's LDS rows plus its 128
   // private rows hold the worst-case number of deferred children; everything else walks the reference's tree.
-  if (sc.wide && !(merged && !rs && !ctx->fast_arith &&
+  if (sc.wide && !(merged && !rs &&
                    sc.wide_stack_need + 1u <= (sc.lds_stack_levels ? sc.lds_stack_levels : sc.stack_entries) + 128u))
     sc.wide = nullptr;
   const auto launch_paths_exact = rs ? ptd_rs::launch_paths : ptd::launch_paths;
-  const auto launch_paths = merged ? ((ctx->fast_arith && !rs) ? ptd_fast::launch_paths_merged : (rs ? ptd_rs::launch_paths_merged : ptd::launch_paths_merged))
-                                   : ((ctx->fast_arith && !rs) ? ptd_fast::launch_paths : launch_paths_exact);  // the fast build has packed entries only
+  // PT_ARITH=fast applies to scenes staged in LDS, which are bound by VALU issue (cfg2 +13 %). Scenes read from global memory wait on
+  // memory: there the fast compilation never gained (round 2: 71.8 against 69.4 ms per launch on the atrium) and round 3 measured it
+  // SLOWER (its register allocation spills inside the walk loops: atrium 1256 / 1714 Mrays/s merged / k_paths against 2052 / 1878), so
+  // those scenes run the exact kernels whatever PT_ARITH says — and stay bit-exact.
+  const bool fast = ctx->fast_arith && sc.scene_in_lds;
+  const auto launch_paths = merged ? (rs ? ptd_rs::launch_paths_merged : ptd::launch_paths_merged) : (fast ? ptd_fast::launch_paths : launch_paths_exact);
   // Concurrent bands (path pipeline): the frame is cut into `conc` bands of tiles, each with its own state, queues and stream,
   // and their launches are enqueued alternately. Every k_paths launch ends with a tail in which most of the GPU idles while the
   // last waves finish their vertices (a 1080p launch is only ~5 rounds of resident waves); the other band's launch fills it.
@@ -1218,6 +1240,7 @@ int render_accum_impl(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev,
     stats_out->scene_in_lds = sc.scene_in_lds;
     stats_out->merged_walk = merged ? 1u : 0u;
     stats_out->bvh_wide4 = sc.wide ? 1u : 0u;
+    stats_out->fast_arith = fast ? 1u : 0u;
     pt_kernel_stats* per[PT_K_COUNT + 1] = {nullptr, &stats_out->extend, &stats_out->shade, &stats_out->shadow, &stats_out->path_kernel};
     stats_out->path_kernel.launches = launches[PT_K_PATHS];
     for (int k = PT_K_EXTEND; k < PT_K_COUNT; ++k) {

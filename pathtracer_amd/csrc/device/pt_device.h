@@ -133,8 +133,4 @@ namespace ptd_fast {  // pt_kernels_fast.hip: k_paths with the shading half on h
 void launch_paths(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity, uint32_t cnt_in,
                   uint32_t cnt_out, uint32_t cnt_zero, uint32_t max_entries, uint32_t block, uint32_t max_blocks,
                   uint32_t max_vertices, uint32_t xcd_chunk, hipStream_t s);
-void launch_paths_merged(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity, uint32_t cnt_in,
-                         uint32_t cnt_out, uint32_t cnt_zero, uint32_t max_entries, uint32_t block, uint32_t max_blocks,
-                         uint32_t max_vertices, uint32_t xcd_chunk, hipStream_t s);
-size_t merged_lds_bytes(const pt_dev_scene& sc, uint32_t block);
 }  // namespace ptd_fast

@@ -1943,6 +1943,7 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_paths(pt_dev_scene sc, pt_de
   flush_tally(walks, st, PT_K_SHADOW);
 }
 
+#ifndef PT_FAST_ARITH  // (the fast-arithmetic compilation is for LDS-resident scenes: pt_context.hip)
 // k_paths for scenes read from global memory with at most two light samples per vertex: same state, same queues, same per-slot
 // order of work, but a vertex's shadow walks ride with the next vertex's closest-hit walk in one loop (merged_walk). The last
 // vertex a slot shades in a launch leaves light samples behind: one more round walks those alone, so nothing pends across launches.
@@ -2052,6 +2053,8 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_paths_merged(pt_dev_scene sc
   flush_tally(tally, st, PT_K_SHADE);
   flush_tally(walks, st, PT_K_SHADOW);
 }
+
+#endif  // !PT_FAST_ARITH
 
 }  // namespace PT_KNS
 using namespace PT_KNS;
@@ -2221,6 +2224,7 @@ void launch_paths(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_st
 #undef PT_LAUNCH_PATHS
 }
 
+#ifndef PT_FAST_ARITH
 // k_paths_merged: scenes read from global memory, at most two light samples per vertex (the caller checks both). LDS per thread:
 // the traversal-stack rows + 80 bytes of stash.
 size_t merged_lds_bytes(const pt_dev_scene& sc, uint32_t block) { return trace_lds_bytes(sc, block) + 80u * static_cast<size_t>(block); }
@@ -2257,6 +2261,8 @@ void launch_paths_merged(const pt_dev_scene& sc, const pt_dev_frame& f, const pt
 #undef PT_LAUNCH_MERGED_BY_SIZE
 #undef PT_LAUNCH_MERGED
 }
+
+#endif  // !PT_FAST_ARITH
 
 #ifndef PT_FAST_ARITH
 void launch_sum_stats(const pt_dev_state& st, hipStream_t s) { hipLaunchKernelGGL(k_sum_stats, dim3(PT_K_COUNT), dim3(256), 0, s, st); }

@@ -44,7 +44,7 @@ def load() -> C.CDLL:
         lib.pt_render_accum_device_noalloc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.pt_resolve_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p]
         for name in ("pt_upload_scene", "pt_render", "pt_render_accum_device", "pt_render_accum_device_noalloc", "pt_resolve_device",
-                     "pt_build_bvh", "pt_build_bvh_mt", "pt_process_scene", "pt_make_push_constants"):
+                     "pt_build_bvh", "pt_build_bvh_mt", "pt_process_scene", "pt_make_push_constants", "pt_build_wide4"):
             getattr(lib, name).restype = C.c_int
         _lib = lib
     return _lib

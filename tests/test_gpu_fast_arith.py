@@ -44,6 +44,7 @@ def test_fast_arithmetic_is_within_the_stated_tolerance(oracle, monkeypatch, sce
     assert (ids == o_ids).mean() >= 0.9999          # north_star; in fact identical:
     assert (ids == o_ids).all()
     assert st["paths"] == o_st["paths"]
+    assert st["scene_in_lds"] == 1 and st["fast_arith"] == 1
     assert np.isfinite(accum).all()
     e = rel_mse(accum, o_accum)
     assert e <= REL_MSE_TOLERANCE, e
@@ -57,33 +58,27 @@ def block_means(accum, n=16):
     return accum[:h, :w].reshape(h // n, n, w // n, n, 4).sum(axis=(1, 3))
 
 
-def test_fast_arithmetic_on_cfg3_at_size(monkeypatch):
-    """The headline scene (253 k triangles, 44 1024^2 textures, 1080p; 64 spp to keep the test short) on the fast build against the
-    exact build's frame, both on the GPU: a scene read from global memory through k_paths_merged, linearly filtered textures whose
-    alpha the shader branches on (the first fast build decoded a 255 byte as 0.99999994 and walked through every textured wall).
-    In an open scene one grazing ray that hits in one build and escapes in the other shifts the pixel's RNG stream (one stream per
-    pixel, Q2) and decorrelates all its later samples, so per pixel the two frames differ by Monte-Carlo noise, not by arithmetic:
-    the yardstick for that is the exact build against ITSELF from another seed; the tolerance of north_star (1e-3) is applied where
-    the noise is averaged out, on 16 x 16 block means."""
+def test_fast_arithmetic_leaves_scenes_read_from_global_memory_exact(monkeypatch):
+    """PT_ARITH=fast is for scenes staged in LDS, which VALU issue bounds. A scene read from global memory waits on memory: the fast
+    compilation never gained there (round 2) and its register allocation made it slower in round 3 (atrium: 1256 against 2052
+    Mrays/s), so pt_render runs the exact kernels on such a scene whatever PT_ARITH says. The headline scene (253 k triangles, 44
+    1024^2 textures; a 480 x 270 frame to keep the test short) must therefore come out bit-identical, and pt_stats must say so."""
     import bench
-    factory, kw, w, h, _, _ = bench.WORKLOADS["atrium1080"]
+    factory, kw, _, _, _, _ = bench.WORKLOADS["atrium1080"]
     packed, frames = None, {}
-    for tag, arith, seed in (("exact", "exact", bench.SEED), ("fast", "fast", bench.SEED), ("reseeded", "exact", bench.SEED + 1)):
+    for arith in ("exact", "fast"):
         monkeypatch.setenv("PT_ARITH", arith)
         r = Renderer(0)
         try:
             if packed is None:
                 packed = r.pack(getattr(scenes, factory)(**kw))
             r.upload(packed)
-            rp = packed.render_params(r.lib, w, h, 64, bench.BG["atrium1080"], seed=seed)
+            rp = packed.render_params(r.lib, 480, 270, 64, bench.BG["atrium1080"], seed=bench.SEED)
             _, accum, ids, st = r.render_params(rp)
-            frames[tag] = (accum, ids, st)
+            frames[arith] = (accum, ids, st)
         finally:
             r.close()
-    (a, ia, sa), (b, ib, sb), (c, _, _) = frames["exact"], frames["fast"], frames["reseeded"]
-    assert (ia == ib).mean() >= 0.9999 and sa["paths"] == sb["paths"] and np.isfinite(b).all()
-    assert abs(sb["rays"] - sa["rays"]) < 1e-3 * sa["rays"]  # the same work, give or take a grazing ray
-    noise = rel_mse(c, a)
-    assert rel_mse(b, a) <= 1.25 * noise, (rel_mse(b, a), noise)              # per pixel: no worse than another seed's noise
-    assert rel_mse(block_means(b), block_means(a)) <= REL_MSE_TOLERANCE     # with the noise averaged out: north_star's tolerance
-    assert (a.view(np.uint32) != b.view(np.uint32)).any()
+    (a, ia, sa), (b, ib, sb) = frames["exact"], frames["fast"]
+    assert sa["scene_in_lds"] == 0 and sa["fast_arith"] == 0 and sb["fast_arith"] == 0
+    assert (ia == ib).all() and (a.view(np.uint32) == b.view(np.uint32)).all()
+    assert {k: v for k, v in sa.items() if not k.endswith("_ms")} == {k: v for k, v in sb.items() if not k.endswith("_ms")}

@@ -168,3 +168,72 @@ print("ok")
     p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PT_RCCL_LIB="/nonexistent/no_such_rccl.so", PT_NO_TORCH_PRELOAD="1"),
                        capture_output=True, text=True, timeout=120)
     assert p.returncode == 0 and "ok" in p.stdout, p.stderr[-2000:]
+
+
+@pytest.mark.parametrize("make", [lambda: scenes.rocks_scene(n_tris=6000), lambda: scenes.soup_scene(3000, seed=4), lambda: scenes.cornell_scene(),
+                                  lambda: scenes.atrium_scene(detail=2, tex_size=16), lambda: scenes.cube_scene()])
+def test_wide4_records_are_a_conservative_cover_of_the_reference_tree(ptlib, make):
+    """pt_build_wide4 (the records PT_BVH=wide4 walks): decoded with the arithmetic of the header, every child box CONTAINS the
+    reference's box of the node it stands for; every leaf of the binary tree is reached exactly once with its triangle range intact;
+    a record holds 2 to 4 children; the stated stack need bounds a depth-first walk."""
+    packed = PackedScene(make(), ptlib)
+    N = packed.packed_nodes
+    count = C.c_uint32(0)
+    need = C.c_uint32(0)
+    assert ptlib.pt_build_wide4(N.ctypes.data_as(C.c_void_p), C.c_uint32(len(N)), None, C.c_uint32(0), C.byref(count), C.byref(need)) == 0
+    rec = np.zeros((count.value, 16), dtype=np.uint32)
+    assert ptlib.pt_build_wide4(N.ctypes.data_as(C.c_void_p), C.c_uint32(len(N)), rec.ctypes.data_as(C.c_void_p), C.c_uint32(len(rec)), C.byref(count),
+                                C.byref(need)) == 0
+    if N[0]["triangle_count"] > 0:
+        assert count.value == 0
+        return
+    # binary leaves by first triangle -> (count, box)
+    leaves = {int(n["left_or_begin"]): n for n in N if n["triangle_count"] > 0 and np.isfinite(n["aabb_min"]).all()}
+    # walk the binary tree to know which leaves are reachable from the root
+    reach, todo = set(), [0]
+    while todo:
+        n = N[todo.pop()]
+        if n["triangle_count"] > 0:
+            reach.add(int(n["left_or_begin"]))
+        else:
+            todo += [int(n["left_or_begin"]), int(n["left_or_begin"]) + 1]
+    seen = []
+    origin = rec[:, 0:3].view(np.float32)
+
+    def boxes(w):
+        ex = int(rec[w, 3])
+        cell = np.array([np.ldexp(np.float32(1.0), ((ex >> (8 * a)) & 255) - 127) for a in range(3)], dtype=np.float32)
+        lo = np.array([[(int(rec[w, 8 + a]) >> (8 * c)) & 255 for a in range(3)] for c in range(4)], dtype=np.float32)
+        hi = np.array([[(int(rec[w, 11 + a]) >> (8 * c)) & 255 for a in range(3)] for c in range(4)], dtype=np.float32)
+        return origin[w] + lo * cell, origin[w] + hi * cell  # float32: the decoder's arithmetic
+
+    def union_of_subtree(w, c, lo, hi):
+        """Check child c of record w against everything below it; returns the deepest stack a walk entering it needs."""
+        e = int(rec[w, 4 + c])
+        if e & 127:
+            first, cnt = e >> 7, e & 127
+            leaf = leaves[first]
+            assert int(leaf["triangle_count"]) == cnt
+            assert (lo[c] <= leaf["aabb_min"]).all() and (hi[c] >= leaf["aabb_max"]).all(), (w, c)
+            seen.append(first)
+            return 0, leaf["aabb_min"], leaf["aabb_max"]
+        return check(e >> 7, lo[c], hi[c])
+
+    def check(w, plo=None, phi=None):
+        lo, hi = boxes(w)
+        kids = [c for c in range(4) if int(rec[w, 4 + c]) != 0xFFFFFFFF]
+        assert 2 <= len(kids) <= 4 and kids == list(range(len(kids)))
+        deepest, ulo, uhi = 0, np.full(3, np.inf, dtype=np.float32), np.full(3, -np.inf, dtype=np.float32)
+        for c in kids:
+            d, blo, bhi = union_of_subtree(w, c, lo, hi)
+            deepest = max(deepest, d)
+            ulo, uhi = np.minimum(ulo, blo), np.maximum(uhi, bhi)
+        if plo is not None:  # the parent's byte box of this record covers everything in it
+            assert (plo <= ulo).all() and (phi >= uhi).all(), w
+        return len(kids) - 1 + deepest, ulo, uhi
+
+    import sys
+    sys.setrecursionlimit(10000)
+    deepest, _, _ = check(0)
+    assert sorted(seen) == sorted(reach)  # every reachable leaf exactly once
+    assert deepest <= need.value
