@@ -157,6 +157,8 @@ struct pt_ctx {
   bool wide4 = false;               // PT_BVH=wide4 (opt-in, NOT bit-exact): k_paths_merged walks 64-byte records of up to four children with 8-bit boxes
   bool merged = true;               // PT_MERGED=0: scenes in global memory with at most two light samples per vertex run k_paths (shadow walks in
                                     // their own phase) instead of k_paths_merged (a vertex's shadow walks ride with the next closest-hit walk)
+  uint32_t pair_order = 0;          // PT_PAIR_ORDER: order of the child-pair records in memory (pt_upload_scene; same results for any value)
+  uint32_t pair_order_levels = 8;   // PT_PAIR_ORDER_LEVELS: levels kept breadth-first by PT_PAIR_ORDER=2
   uint32_t merged_lds_stack = 9;    // PT_MERGED_LDS_STACK: LDS stack rows per lane of k_paths_merged, deeper rows in private memory. 36 B + 80 B of stash per
                                     // lane keep 20 waves per CU inside the 160 KB (measured, rocks / atrium Mrays/s: 4 rows 1461 / 1961, 6: 1529 / 2025,
                                     // 8: 1601 / 2038, 9: 1623 / 2040, 10: 1544 / 1933, 11: 1549 / 1933, 16: fewer waves fit)
@@ -447,6 +449,9 @@ extern "C" pt_ctx* pt_create(int device) {
   if (const char* e = std::getenv("PT_CHILD_ENTRIES")) ctx->child_entries = std::atoi(e) != 0;
   if (const char* e = std::getenv("PT_MERGED")) ctx->merged = std::atoi(e) != 0;
   if (const char* e = std::getenv("PT_BVH")) ctx->wide4 = std::string(e) == "wide4";
+  if (const char* e = std::getenv("PT_PAIR_ORDER")) ctx->pair_order = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
+  if (ctx->pair_order > 4) ctx->pair_order = 0;
+  if (const char* e = std::getenv("PT_PAIR_ORDER_LEVELS")) ctx->pair_order_levels = std::min(30ul, std::strtoul(e, nullptr, 10));
   if (const char* e = std::getenv("PT_MERGED_LDS_STACK")) ctx->merged_lds_stack = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   if (ctx->merged_lds_stack > 64) ctx->merged_lds_stack = 64;
   if (const char* e = std::getenv("PT_CONCURRENT_BANDS")) ctx->concurrent_bands = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
@@ -716,15 +721,66 @@ static int upload_one(pt_ctx* ctx, const pt_scene_desc* s) {
     const pt_packed_bvh_node* N = s->bvh_nodes;
     std::vector<uint32_t> order;  // inner nodes, breadth-first
     std::vector<uint32_t> record_of(s->bvh_node_count, 0xFFFFFFFFu);
+    constexpr uint32_t kPad = 0xFFFFFFFFu;  // order[] entry of a padding record (sibling order only)
+    const auto inner = [&](uint32_t c) { return N[c].triangle_count == 0; };
     if (N[0].triangle_count == 0) order.push_back(0);
-    for (size_t head = 0; head < order.size(); ++head) {
-      const uint32_t n = order[head];
-      record_of[n] = static_cast<uint32_t>(head);
-      for (uint32_t side = 0; side < 2; ++side) {
-        const uint32_t c = N[n].left_or_begin + side;
-        if (N[c].triangle_count == 0) order.push_back(c);
+    if (ctx->pair_order == 0 || order.empty()) {
+      for (size_t head = 0; head < order.size(); ++head) {
+        const uint32_t n = order[head];
+        for (uint32_t side = 0; side < 2; ++side) {
+          const uint32_t c = N[n].left_or_begin + side;
+          if (inner(c)) order.push_back(c);
+        }
+      }
+    } else {
+      // Experiment orders (same records, other addresses: results identical by construction):
+      //   1 depth-first, a record followed by everything under its left child (the reference's own numbering)
+      //   2 the top `pair_order_levels` levels breadth-first, each sub-tree below them depth-first
+      //   3 siblings adjacent (two inner children of a record next to each other, then everything under the left, then the right)
+      //   4 as 3, with sibling pairs aligned to 128 bytes (a padding record where needed)
+      order.clear();
+      std::vector<uint32_t> roots{0u};
+      if (ctx->pair_order == 2) {
+        for (uint32_t level = 0; level < ctx->pair_order_levels; ++level) {
+          std::vector<uint32_t> next;
+          for (uint32_t n : roots) {
+            order.push_back(n);
+            for (uint32_t side = 0; side < 2; ++side)
+              if (inner(N[n].left_or_begin + side)) next.push_back(N[n].left_or_begin + side);
+          }
+          roots.swap(next);
+        }
+      }
+      std::vector<uint32_t> stack;
+      for (uint32_t root : roots) {
+        if (ctx->pair_order <= 2) {
+          stack.assign(1, root);
+          while (!stack.empty()) {
+            const uint32_t n = stack.back();
+            stack.pop_back();
+            order.push_back(n);
+            const uint32_t l = N[n].left_or_begin;
+            if (inner(l + 1)) stack.push_back(l + 1);
+            if (inner(l)) stack.push_back(l);
+          }
+        } else {
+          order.push_back(root);
+          stack.assign(1, root);  // records already placed whose children are not
+          while (!stack.empty()) {
+            const uint32_t n = stack.back();
+            stack.pop_back();
+            const uint32_t l = N[n].left_or_begin;
+            if (ctx->pair_order == 4 && inner(l) && inner(l + 1) && (order.size() & 1u)) order.push_back(kPad);
+            if (inner(l)) order.push_back(l);
+            if (inner(l + 1)) order.push_back(l + 1);
+            if (inner(l + 1)) stack.push_back(l + 1);
+            if (inner(l)) stack.push_back(l);
+          }
+        }
       }
     }
+    for (size_t p = 0; p < order.size(); ++p)
+      if (order[p] != kPad) record_of[order[p]] = static_cast<uint32_t>(p);
     // record_of[] of a child is assigned when the child is dequeued, i.e. after its parent: two passes
     struct PairRecord {
       float box[12];
@@ -733,6 +789,10 @@ static int upload_one(pt_ctx* ctx, const pt_scene_desc* s) {
     static_assert(sizeof(PairRecord) == 64, "layout");
     std::vector<PairRecord> rec(order.size());
     for (size_t p = 0; p < order.size(); ++p) {
+      if (order[p] == kPad) {
+        std::memset(&rec[p], 0, sizeof(PairRecord));
+        continue;
+      }
       for (uint32_t side = 0; side < 2; ++side) {
         const uint32_t c = N[order[p]].left_or_begin + side;
         const pt_packed_bvh_node& r = N[c];

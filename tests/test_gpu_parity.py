@@ -133,6 +133,8 @@ def test_rank_split_matches_oracle_per_rank(renderer, oracle):
                                  {"PT_CONCURRENT_BANDS": "1"}, {"PT_CHILD_ENTRIES": "0"},
                                  {"PT_MERGED": "0"}, {"PT_MERGED_LDS_STACK": "2"}, {"PT_MERGED_LDS_STACK": "0", "PT_PATHS_VERTICES": "3"},
                                  {"PT_CHILD_ENTRIES": "0", "PT_MERGED_LDS_STACK": "3", "PT_PATHS_BLOCK_THREADS": "256"},
+                                 {"PT_PAIR_ORDER": "1"}, {"PT_PAIR_ORDER": "2", "PT_PAIR_ORDER_LEVELS": "3"}, {"PT_PAIR_ORDER": "4", "PT_MERGED": "0"},
+                                 {"PT_PAIR_ORDER": "3", "PT_CHILD_ENTRIES": "0"},
                                  {"PT_CHILD_ENTRIES": "0", "PT_PIPELINE": "wavefront", "PT_LDS_STACK": "3"}])
 def test_alternative_pipelines_give_the_same_bits(oracle, monkeypatch, env):
     """The wavefront pipeline (k_extend + k_shade, fused or with the split k_shadow, lazy or per-iteration
