@@ -1577,6 +1577,11 @@ __global__ __launch_bounds__(256, ALL_OPAQUE ? PT_SHADOW_MIN_WAVES_OPAQUE : PT_S
 #define PT_MERGED_COLD 0
 #endif
 constexpr uint32_t kMergedPark = PT_MERGED_PARK;
+// Experiment: when a far child is deferred, touch one word of what its later visit will fetch (its pair record, or its first
+// triangle), so that the line is on its way when the entry is popped. 1: every deferred child, 2: inner children only.
+#ifndef PT_TOUCH_FAR
+#define PT_TOUCH_FAR 0
+#endif
 
 //
 // `cold` is a private (scratch) array: it holds the first hit of a light sample that may be transparent until the walk is over
@@ -1648,6 +1653,9 @@ __device__ __forceinline__ void merged_walk(const pt_dev_scene& sc, const ShadeD
   bool live = false;
   constexpr uint32_t kDeep = WIDE ? kDeepLevelsWide : kDeepLevels;
   uint32_t deep[kDeep];  // rows beyond the lane's LDS rows (private memory), as in traverse()
+#if PT_TOUCH_FAR
+  uint32_t touched = 0;  // the word a touch load returned: only ever handed to an empty asm, one trip later
+#endif
   auto push = [&](uint32_t e) {
     if (sp != tr.stack_end) {
       stack_store(sp, e);
@@ -1743,6 +1751,13 @@ __device__ __forceinline__ void merged_walk(const pt_dev_scene& sc, const ShadeD
             const uint32_t e = (ref << 1) | (go_left ? 1u : 0u);
 #endif
             push(e);
+#if PT_TOUCH_FAR && PT_STACK_CHILD
+            asm volatile("" ::"v"(touched));  // (the previous touch has arrived: this trip's record was fetched after it)
+            if (PT_TOUCH_FAR == 1 || (e & 127u) == 0u) {
+              const float4* at = (e & 127u) ? tr.tri_pos + 3u * static_cast<size_t>(e >> 7) : tr.pairs + 4u * static_cast<size_t>(e >> 7);
+              touched = *reinterpret_cast<const uint32_t*>(at);  // (a plain load: volatile would make it system-coherent, past the caches)
+            }
+#endif
           }
           ref = go_left ? fbits(q3.x) : fbits(q3.z);
           cnt = go_left ? fbits(q3.y) : fbits(q3.w);
