@@ -159,7 +159,8 @@ struct pt_ctx {
                                     // their own phase) instead of k_paths_merged (a vertex's shadow walks ride with the next closest-hit walk)
   uint32_t pair_order = 0;          // PT_PAIR_ORDER: order of the child-pair records in memory (pt_upload_scene; same results for any value)
   uint32_t pair_order_levels = 8;   // PT_PAIR_ORDER_LEVELS: levels kept breadth-first by PT_PAIR_ORDER=2
-  uint32_t merged_lds_stack = 9;    // PT_MERGED_LDS_STACK: LDS stack rows per lane of k_paths_merged, deeper rows in private memory. 36 B + 80 B of stash per
+  uint32_t merged_lds_stack = 0;    // 1 + PT_MERGED_LDS_STACK, 0: unset = 9 rows with two light samples per vertex, 16 with one (pt_render). LDS stack rows per
+                                    // lane of k_paths_merged, deeper rows in private memory. With two samples 36 B + 80 B of stash per
                                     // lane keep 20 waves per CU inside the 160 KB (measured, rocks / atrium Mrays/s: 4 rows 1461 / 1961, 6: 1529 / 2025,
                                     // 8: 1601 / 2038, 9: 1623 / 2040, 10: 1544 / 1933, 11: 1549 / 1933, 16: fewer waves fit)
   bool child_entries = true;        // PT_CHILD_ENTRIES=0: traversal-stack entries as (record, side) even where the scene allows (ref << 7 | cnt)
@@ -452,8 +453,7 @@ extern "C" pt_ctx* pt_create(int device) {
   if (const char* e = std::getenv("PT_PAIR_ORDER")) ctx->pair_order = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   if (ctx->pair_order > 4) ctx->pair_order = 0;
   if (const char* e = std::getenv("PT_PAIR_ORDER_LEVELS")) ctx->pair_order_levels = std::min(30ul, std::strtoul(e, nullptr, 10));
-  if (const char* e = std::getenv("PT_MERGED_LDS_STACK")) ctx->merged_lds_stack = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
-  if (ctx->merged_lds_stack > 64) ctx->merged_lds_stack = 64;
+  if (const char* e = std::getenv("PT_MERGED_LDS_STACK")) ctx->merged_lds_stack = 1u + std::min(64u, static_cast<uint32_t>(std::strtoul(e, nullptr, 10)));
   if (const char* e = std::getenv("PT_CONCURRENT_BANDS")) ctx->concurrent_bands = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   if (const char* e = std::getenv("PT_BAND_MIN_TILES")) ctx->band_min_tiles = static_cast<uint32_t>(std::strtoul(e, nullptr, 10));
   if (ctx->band_min_tiles < 1) ctx->band_min_tiles = 1;
@@ -1009,7 +1009,9 @@ int render_accum_impl(pt_ctx* ctx, const pt_render_params* p, float4* accum_dev,
   const int pipeline = no_alloc ? 0 : ctx->pipeline;
   // k_paths_merged: the path pipeline on a scene read from global memory whose vertices draw at most two light samples (its two stash slots)
   const bool merged = pipeline == 0 && ctx->merged && !sc.scene_in_lds && n_lights <= 2u;
-  const uint32_t lds_stack = merged ? ctx->merged_lds_stack : ctx->lds_stack;
+  // (one light sample per vertex: 40 bytes of stash per lane instead of 80, so 16 rows fit where 9 do with two — rocks 64 spp, rows
+  // 9 / 11 / 13 / 16 / 19 / 20: 1672 / 1700 / 1709 / 1710 / 1707 / 1609 Mrays/s)
+  const uint32_t lds_stack = merged ? (ctx->merged_lds_stack ? ctx->merged_lds_stack - 1u : (ptd::merged_stash_samples(sc, n_lights) > 1u ? 9u : 16u)) : ctx->lds_stack;
   static_assert(PT_DEEP_LEVELS == 48, "the private overflow rows of traverse() (pt_kernels.hip, kDeepLevels) bound the inequality below");
   if (!sc.scene_in_lds && lds_stack && lds_stack < sc.stack_entries && sc.stack_entries <= lds_stack + PT_DEEP_LEVELS) {
     sc.lds_stack_levels = lds_stack;  // short LDS stack, the rest of the depth in private memory (kDeepLevels = 48 rows)

@@ -106,7 +106,8 @@ void launch_paths(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_st
 void launch_paths_merged(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity, uint32_t cnt_in,
                          uint32_t cnt_out, uint32_t cnt_zero, uint32_t max_entries, uint32_t block, uint32_t max_blocks,
                          uint32_t max_vertices, uint32_t xcd_chunk, hipStream_t s);
-size_t merged_lds_bytes(const pt_dev_scene& sc, uint32_t block);
+uint32_t merged_stash_samples(const pt_dev_scene& sc, uint32_t n_lights);  // light samples per vertex the launched k_paths_merged has stash for (1 or 2)
+size_t merged_lds_bytes(const pt_dev_scene& sc, uint32_t block, uint32_t n_lights);
 void launch_sum_stats(const pt_dev_state& st, hipStream_t s);
 void launch_finalize(const pt_dev_frame& f, const pt_dev_state& st, float4* accum_out, uint32_t* primary_out, hipStream_t s);
 void launch_resolve(const float4* accum, uint32_t pixel_count, uint32_t* rgba8, hipStream_t s);
@@ -126,7 +127,8 @@ void launch_paths(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_st
 void launch_paths_merged(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity, uint32_t cnt_in,
                          uint32_t cnt_out, uint32_t cnt_zero, uint32_t max_entries, uint32_t block, uint32_t max_blocks,
                          uint32_t max_vertices, uint32_t xcd_chunk, hipStream_t s);
-size_t merged_lds_bytes(const pt_dev_scene& sc, uint32_t block);
+uint32_t merged_stash_samples(const pt_dev_scene& sc, uint32_t n_lights);  // light samples per vertex the launched k_paths_merged has stash for (1 or 2)
+size_t merged_lds_bytes(const pt_dev_scene& sc, uint32_t block, uint32_t n_lights);
 }  // namespace ptd_rs
 
 namespace ptd_fast {  // pt_kernels_fast.hip: k_paths with the shading half on hardware-approximate arithmetic (PT_ARITH=fast)

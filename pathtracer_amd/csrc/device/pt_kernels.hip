@@ -1557,7 +1557,7 @@ __global__ __launch_bounds__(256, ALL_OPAQUE ? PT_SHADOW_MIN_WAVES_OPAQUE : PT_S
 // lets the sample through, a provably opaque hit (tri_pos tag) blocks it, and only a hit on a surface that may be transparent goes on
 // with the reference's step-by-step walk (shadow_walk<RESUME>, lanes in lock step: rare — cloth, glass).
 // A lane that finishes a job parks. Parked lanes are served together — results booked, next job started (three IEEE divides for
-// 1 / d) — once kMergedPark of them wait or nobody is walking: serving each lane the moment it parks would run that block up to 192
+// 1 / d) — once kMergedPark<> of them wait or nobody is walking: serving each lane the moment it parks would run that block up to 192
 // times per wave and phase for a lane or two at a time. Measured (same box, 1080p, rocks 64 spp / atrium 36 spp, Mrays/s; k_paths
 // 1511 / 1878): park 1: 1598 / 1857, 2: 1569 / 1874, 6: 1555 / 1924, 8: 1549 / 1933, 12: 1530 / 1928, 24: 1455 / 1861 (11 LDS rows).
 #ifndef PT_MERGED_PARK
@@ -1576,7 +1576,13 @@ __global__ __launch_bounds__(256, ALL_OPAQUE ? PT_SHADOW_MIN_WAVES_OPAQUE : PT_S
 #ifndef PT_MERGED_COLD
 #define PT_MERGED_COLD 0
 #endif
-constexpr uint32_t kMergedPark = PT_MERGED_PARK;
+// All-opaque scenes (cfg4): shadow jobs are any-hit walks, short, and their serving block is light (no first hit to keep): served at
+// once, without the vote. Threshold 8 / 4 / 2 / 1: rocks 1615 / 1635 / 1637 / 1668, soup 1639 / 1674 / 1687 / 1707 Mrays/s (9 LDS rows).
+#ifndef PT_MERGED_PARK_OPAQUE
+#define PT_MERGED_PARK_OPAQUE 1
+#endif
+template <bool ALL_OPAQUE>
+constexpr uint32_t kMergedPark = ALL_OPAQUE ? PT_MERGED_PARK_OPAQUE : PT_MERGED_PARK;
 // Experiment: when a far child is deferred, touch one word of what its later visit will fetch (its pair record, or its first
 // triangle), so that the line is on its way when the entry is popped. 1: every deferred child, 2: inner children only.
 #ifndef PT_TOUCH_FAR
@@ -1787,8 +1793,8 @@ __device__ __forceinline__ void merged_walk(const pt_dev_scene& sc, const ShadeD
       }
     }
     const bool parked = !live && cur != 0u;
-    const uint64_t parked_mask = __ballot(parked);
-    if (parked_mask != 0 && (__ballot(live) == 0 || static_cast<uint32_t>(__popcll(parked_mask)) >= kMergedPark)) {
+    const uint64_t parked_mask = __ballot(parked);  // (a threshold of 1 folds to: every parked lane at once)
+    if (parked_mask != 0 && (__ballot(live) == 0 || static_cast<uint32_t>(__popcll(parked_mask)) >= kMergedPark<ALL_OPAQUE>)) {
       if (parked) {
         if (cur != 4u) {
           float v;
@@ -1962,7 +1968,11 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_paths(pt_dev_scene sc, pt_de
 // k_paths for scenes read from global memory with at most two light samples per vertex: same state, same queues, same per-slot
 // order of work, but a vertex's shadow walks ride with the next vertex's closest-hit walk in one loop (merged_walk). The last
 // vertex a slot shades in a launch leaves light samples behind: one more round walks those alone, so nothing pends across launches.
-template <bool ALL_OPAQUE, int MIN_WAVES, bool TEXTURED, bool WIDE = false>
+// SAMPLES: light samples per vertex the stash has room for (40 bytes each). One-sample scenes (a sun and nothing else: cfg4) get a
+// kernel of their own for all-opaque untextured scenes, whose LDS then holds 16 stack rows where two samples leave room for 9;
+// a compile-time parameter because the two-sample kernels' register allocation does not survive ANY change to this address
+// arithmetic (a sample-major layout without the parameter: cfg3 2048 -> 1239 Mrays/s, the pair record's tuple spill back).
+template <bool ALL_OPAQUE, int MIN_WAVES, bool TEXTURED, bool WIDE = false, uint32_t SAMPLES = 2>
 __global__ __launch_bounds__(256, MIN_WAVES) void k_paths_merged(pt_dev_scene sc, pt_dev_frame f, pt_dev_state st, uint32_t parity,
                                                                           uint32_t cnt_in, uint32_t cnt_out, uint32_t cnt_zero,
                                                                           uint32_t max_vertices, uint32_t xcd_chunk) {
@@ -1980,10 +1990,10 @@ __global__ __launch_bounds__(256, MIN_WAVES) void k_paths_merged(pt_dev_scene sc
   if (vblock * blockDim.x < n) {  // block-uniform
     const Tracer tr = make_tracer<false>(sc, lds_dyn);
     const ShadeData sd = make_shade_data<false>(sc, tr, lds_dyn);
-    // LDS: [stack rows x blockDim words | stash: 4 quads x blockDim | 2 pairs x blockDim]
+    // LDS: [stack rows x blockDim words | stash: 2 quads per light sample x blockDim | a pair per light sample x blockDim]
     const uint32_t rows = sc.lds_stack_levels ? sc.lds_stack_levels : sc.stack_entries;
     const uint32_t stash_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_dyn + static_cast<size_t>(blockDim.x) * rows));
-    const Stash stash{stash_base + 16u * threadIdx.x, 16u * blockDim.x, stash_base + 64u * blockDim.x + 8u * threadIdx.x, 8u * blockDim.x};
+    const Stash stash{stash_base + 16u * threadIdx.x, 16u * blockDim.x, stash_base + 32u * SAMPLES * blockDim.x + 8u * threadIdx.x, 8u * blockDim.x};
     for (uint32_t base = vblock * blockDim.x; base < n; base += gridDim.x * blockDim.x) {  // block-uniform trip count
       const uint32_t gid = base + threadIdx.x;
       bool alive = false;
@@ -2241,8 +2251,11 @@ void launch_paths(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_st
 
 #ifndef PT_FAST_ARITH
 // k_paths_merged: scenes read from global memory, at most two light samples per vertex (the caller checks both). LDS per thread:
-// the traversal-stack rows + 80 bytes of stash.
-size_t merged_lds_bytes(const pt_dev_scene& sc, uint32_t block) { return trace_lds_bytes(sc, block) + 80u * static_cast<size_t>(block); }
+// the traversal-stack rows + 40 bytes of stash per light sample of a vertex the kernel has room for.
+uint32_t merged_stash_samples(const pt_dev_scene& sc, uint32_t n_lights) { return (n_lights <= 1u && sc.all_opaque && !sc.any_texture) ? 1u : 2u; }
+size_t merged_lds_bytes(const pt_dev_scene& sc, uint32_t block, uint32_t n_lights) {
+  return trace_lds_bytes(sc, block) + 40u * merged_stash_samples(sc, n_lights) * static_cast<size_t>(block);
+}
 
 void launch_paths_merged(const pt_dev_scene& sc, const pt_dev_frame& f, const pt_dev_state& st, uint32_t parity, uint32_t cnt_in,
                          uint32_t cnt_out, uint32_t cnt_zero, uint32_t max_entries, uint32_t block, uint32_t max_blocks,
@@ -2254,8 +2267,10 @@ void launch_paths_merged(const pt_dev_scene& sc, const pt_dev_frame& f, const pt
     const uint32_t round = 8u * xcd_chunk;
     grid = (grid + round - 1u) / round * round;
   }
-  const size_t lds = merged_lds_bytes(sc, block);
+  const uint32_t n_lights = sc.directional_light_count + sc.point_light_count + (f.pc.emissive_triangle_count ? 1u : 0u);
+  const size_t lds = merged_lds_bytes(sc, block, n_lights);
   const bool textured = sc.any_texture != 0;
+  const bool one_sample = merged_stash_samples(sc, n_lights) == 1u;
 #if PT_STACK_CHILD && !defined(PT_FAST_ARITH)  // the wide4 walk exists in the exact compilation only (its entries are packed children)
 #define PT_LAUNCH_MERGED(B, W, T)                                                                                                                \
   do {                                                                                                                                           \
@@ -2271,7 +2286,13 @@ void launch_paths_merged(const pt_dev_scene& sc, const pt_dev_frame& f, const pt
     if (textured) PT_LAUNCH_MERGED(B, PT_MERGED_MIN_WAVES, true);        \
     else PT_LAUNCH_MERGED(B, PT_MERGED_MIN_WAVES, false);                \
   } while (0)
-  if (sc.all_opaque) PT_LAUNCH_MERGED_BY_SIZE(true);
+  if (one_sample) {  // all-opaque, untextured, one light sample per vertex (merged_stash_samples)
+#if PT_STACK_CHILD && !defined(PT_FAST_ARITH)
+    if (sc.wide) hipLaunchKernelGGL((k_paths_merged<true, PT_MERGED_MIN_WAVES, false, true, 1u>), dim3(grid), dim3(block), lds, s, sc, f, st, parity, cnt_in, cnt_out, cnt_zero, max_vertices, xcd_chunk);
+    else
+#endif
+      hipLaunchKernelGGL((k_paths_merged<true, PT_MERGED_MIN_WAVES, false, false, 1u>), dim3(grid), dim3(block), lds, s, sc, f, st, parity, cnt_in, cnt_out, cnt_zero, max_vertices, xcd_chunk);
+  } else if (sc.all_opaque) PT_LAUNCH_MERGED_BY_SIZE(true);
   else PT_LAUNCH_MERGED_BY_SIZE(false);
 #undef PT_LAUNCH_MERGED_BY_SIZE
 #undef PT_LAUNCH_MERGED

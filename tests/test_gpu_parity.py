@@ -147,6 +147,7 @@ def test_alternative_pipelines_give_the_same_bits(oracle, monkeypatch, env):
         compare(r, oracle, scenes.cornell_scene(), 96, 54, 9, seed=32)                                # LDS-resident, all opaque
         compare(r, oracle, scenes.textured_scene(), 160, 90, 9, seed=33)                              # global memory, alpha, 2 lights
         compare(r, oracle, scenes.soup_scene(20000, emissive_every=50), 96, 54, 9, seed=34)           # global memory, all opaque
+        compare(r, oracle, scenes.soup_scene(12000, seed=9), 96, 54, 9, seed=35)                      # ... with ONE light sample per vertex (its own merged kernel)
     finally:
         r.close()
 
