@@ -16,16 +16,23 @@ from pathtracer_amd.renderer import Renderer  # noqa: E402
 COUNTERS = ["paths", "rays", "node_visits", "tri_tests", "hits_shaded", "texture_taps", "shaded_vertices", "nan_samples"]
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
 count = int(sys.argv[2]) if len(sys.argv) > 2 else 100
-ENVS = [{}, {"PT_CONCURRENT_BANDS": "3", "PT_BAND_MIN_TILES": "1"}, {"PT_PIPELINE": "wavefront", "PT_LDS_STACK": "4"},
-        {"PT_PIPELINE": "wavefront", "PT_TAIL_ENTRIES": "0"}, {"PT_LDS_SCENE_BYTES": "0", "PT_CONCURRENT_BANDS": "2", "PT_BAND_MIN_TILES": "2"}]
+# round 3: the random scenes are small, so PT_LDS_SCENE_BYTES=0 is what sends them through the global-memory kernels (k_paths_merged
+# with two or one light samples per vertex, k_paths beyond two), under short LDS stacks, other record orders and the (record, side) entries
+G = {"PT_LDS_SCENE_BYTES": "0"}
+ENVS = [{}, dict(G), {"PT_CONCURRENT_BANDS": "3", "PT_BAND_MIN_TILES": "1"}, {"PT_PIPELINE": "wavefront", "PT_LDS_STACK": "4"},
+        {"PT_PIPELINE": "wavefront", "PT_TAIL_ENTRIES": "0"}, {**G, "PT_CONCURRENT_BANDS": "2", "PT_BAND_MIN_TILES": "2"},
+        {**G, "PT_MERGED_LDS_STACK": "2", "PT_PATHS_VERTICES": "3"}, {**G, "PT_MERGED": "0"}, {**G, "PT_PAIR_ORDER": "4"},
+        {**G, "PT_CHILD_ENTRIES": "0", "PT_MERGED_LDS_STACK": "0"}]
+KNOBS = sorted({k for e in ENVS for k in e})
 oracle = oracle_lib.load()
 bad = 0
+kinds = {}
 for e_i, env in enumerate(ENVS):
-    for k in ("PT_CONCURRENT_BANDS", "PT_BAND_MIN_TILES", "PT_PIPELINE", "PT_LDS_STACK", "PT_TAIL_ENTRIES", "PT_LDS_SCENE_BYTES"):
+    for k in KNOBS:
         os.environ.pop(k, None)
     os.environ.update(env)
     r = Renderer(0)
-    n = count if e_i == 0 else max(count // 4, 1)
+    n = count if e_i <= 1 else max(count // 4, 1)
     for i in range(n):
         seed = first + i
         sw = (seed & 1, (seed >> 1) & 1, (seed >> 2) & 1)
@@ -42,6 +49,7 @@ for e_i, env in enumerate(ENVS):
         if not ok:
             bad += 1
             print(f"MISMATCH env {env} seed {seed} switches {sw} {w}x{h} spp {spp}", flush=True)
+    kinds[(st["merged_walk"], st["scene_in_lds"])] = kinds.get((st["merged_walk"], st["scene_in_lds"]), 0) + 1
     print(f"env {env}: {n} scenes done, mismatches so far {bad}", flush=True)
     r.close()
 print("FUZZ", "FAILED" if bad else "ok", flush=True)
