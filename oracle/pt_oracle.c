@@ -374,6 +374,7 @@ typedef struct {
   int any_hit_shadows; /* ORC_FLAG_ANYHIT_OPAQUE_SHADOW and the scene is provably all-opaque */
   int cull_behind;     /* ORC_FLAG_CULL_BEHIND: skip boxes with t_far < 0 (checker mirror of the HIP path) */
   int self_first;      /* ORC_FLAG_SELF_FIRST: any-hit shadow queries test the shading point's own triangle first (checker mirror of the HIP path) */
+  int stale_skip;      /* ORC_FLAG_STALE_SKIP: closest-hit walks of path rays skip deferred inner nodes whose entry distance is no longer below the hit (checker mirror) */
   int span_order;      /* ORC_FLAG_ANYHIT_SPAN_ORDER: any-hit walks enter the child the ray stays inside longer first (checker mirror of the HIP path) */
   uint32_t self_tri;   /* the triangle the current vertex lies on */
   const uint8_t* mat_opaque; /* ORC_FLAG_OPAQUE_TRIANGLES: per material, 1 = provably alpha == 1.0 (checker mirror of the HIP path), else NULL */
@@ -623,6 +624,14 @@ static void ray_scene_intersect_ex(shctx* c, const ray_t* ray, isect_t* info, in
   while (top != 0) {
     const float entry_dist = top <= 400u ? dstack[top - 1] : -ORC_INFINITY;
     const pt_packed_bvh_node* node = &nodes[stack[--top]];
+    if (c->stale_skip && !any_hit && !c->in_shadow_walk && node->triangle_count == 0 && top < 400u) {
+      /* the stale-entry skip (ORC_FLAG_STALE_SKIP; mirror of a round-3 experiment kernel): the entry distance noted when the child
+       * was deferred is no longer below the closest hit -> the node is not visited. Exact: its
+       * children's boxes lie inside its own and the slab arithmetic is monotonic in the bounds, so both would fail `dist < t`. (In
+       * the kernel only DEFERRED children carry a distance; the near child, entered at once, passed `dist < t` a moment ago with the
+       * same t: never stale here either.) */
+      if (entry_dist >= info->t) continue;
+    }
     ++trips;
     int stale = 0;
     if (g_popcull_on && !any_hit) {
@@ -1099,6 +1108,7 @@ typedef struct {
   int cull_behind;
   int self_first;
   int span_order;
+  int stale_skip;
   const uint8_t* mat_opaque;
   pt_stats st;
 } worker_arg;
@@ -1113,6 +1123,7 @@ static void* worker_main(void* p) {
   c.cull_behind = w->cull_behind;
   c.self_first = w->self_first;
   c.span_order = w->span_order;
+  c.stale_skip = w->stale_skip;
   c.mat_opaque = w->mat_opaque;
   c.self_tri = ORC_NO_HIT;
   c.stack = (uint32_t*)malloc(sizeof(uint32_t) * (w->sc->bvh_max_depth + 64)); /* main.comp:263-265 */
@@ -1188,6 +1199,7 @@ int orc_render_ex(const pt_scene_desc* scene, const pt_render_params* params, ui
     w->cull_behind = (flags & ORC_FLAG_CULL_BEHIND) != 0;
     w->self_first = any_hit && (flags & ORC_FLAG_SELF_FIRST) != 0;
     w->span_order = any_hit && (flags & ORC_FLAG_ANYHIT_SPAN_ORDER) != 0;
+    w->stale_skip = (flags & ORC_FLAG_STALE_SKIP) != 0;
     w->mat_opaque = mat_opaque;
     if (num_threads > 1) pthread_create(&th[i], NULL, worker_main, w);
     else worker_main(w);

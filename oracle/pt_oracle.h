@@ -59,6 +59,11 @@ int orc_render(const pt_scene_desc* scene, const pt_render_params* params, uint8
  * bytes are all 255), the walk returns 0 (main.comp:325) without get_interpolated_data, the material fetch and the texture tap: the
  * same result with fewer hits_shaded / texture_taps. */
 #define ORC_FLAG_OPAQUE_TRIANGLES 16u
+/* ORC_FLAG_STALE_SKIP: a closest-hit walk of a path ray does not visit a deferred INNER node whose entry distance, noted when the
+ * node was deferred, is no longer below the closest hit. The image cannot change (the node's children lie inside its box and the
+ * slab arithmetic is monotonic in the bounds, so both would be culled); node_visits shrinks by 4-5 %. A MODEL and the checker
+ * mirror of a kernel that was built in round 3 and measured slower: no shipped HIP kernel sets it. */
+#define ORC_FLAG_STALE_SKIP 32u
 int orc_render_ex(const pt_scene_desc* scene, const pt_render_params* params, uint8_t* rgba8_out,
                   float* accum_out, uint32_t* primary_id_out, pt_stats* stats_out, int num_threads,
                   uint32_t y_begin, uint32_t y_end, uint32_t flags);

@@ -43,7 +43,7 @@ for e_i, env in enumerate(ENVS):
         rp = packed.render_params(r.lib, w, h, spp, (0.239, 0.239, 0.239), seed)
         rgba, accum, ids, st = r.render_params(rp)
         o_rgba, o_accum, o_ids, _ = oracle_lib.render(oracle, packed, rp, threads=16)
-        o_st = oracle_lib.render(oracle, packed, rp, threads=16, flags=oracle_lib.mirror_flags(st["scene_in_lds"]))[3]
+        o_st = oracle_lib.render(oracle, packed, rp, threads=16, flags=oracle_lib.mirror_flags(st))[3]
         ok = ((ids == o_ids).all() and (accum.view(np.uint32) == o_accum.view(np.uint32)).all() and (rgba == o_rgba).all()
               and all(st[k] == o_st[k] for k in COUNTERS))
         if not ok:

@@ -32,14 +32,17 @@ CULL_BEHIND = 2
 SELF_FIRST = 4
 ANYHIT_SPAN_ORDER = 8
 OPAQUE_TRIANGLES = 16
+STALE_SKIP = 32  # model / mirror of the round-3 experiment kernel that skipped stale inner stack entries (exact; node_visits shrinks; not shipped)
 # the checker modes that reproduce the HIP path's work counters (identical images by construction, tests/test_oracle_shader.py):
 GPU_MIRROR = ANYHIT_OPAQUE_SHADOW | CULL_BEHIND | SELF_FIRST | ANYHIT_SPAN_ORDER | OPAQUE_TRIANGLES  # scenes read from global memory
 GPU_MIRROR_LDS = ANYHIT_OPAQUE_SHADOW | CULL_BEHIND | OPAQUE_TRIANGLES  # scenes staged in LDS: no own-triangle-first test, any-hit walks nearer-first
 
 
-def mirror_flags(scene_in_lds):
-    """Checker flags for a render whose pt_stats.scene_in_lds the HIP path reported."""
-    return GPU_MIRROR_LDS if scene_in_lds else GPU_MIRROR
+def mirror_flags(st):
+    """Checker flags for a render whose pt_stats the HIP path reported (the stats dict; a bare scene_in_lds value is accepted too)."""
+    if not isinstance(st, dict):
+        return GPU_MIRROR_LDS if st else GPU_MIRROR
+    return (GPU_MIRROR_LDS if st["scene_in_lds"] else GPU_MIRROR) | (STALE_SKIP if st.get("stale_skip") else 0)
 
 
 def render(lib, packed, rp, threads=8, rows=None, want_ids=True, flags=0):

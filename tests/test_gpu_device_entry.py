@@ -66,7 +66,7 @@ def test_three_way_strata_split_summed_on_the_device_equals_the_oracle(renderer,
             renderer._check(rc, "pt_render_accum_device")
             total += part
             stream.synchronize()
-            _, o_accum, o_ids, o_st = oracle_lib.render(oracle, packed, rp, threads=8, flags=oracle_lib.mirror_flags(st.scene_in_lds))
+            _, o_accum, o_ids, o_st = oracle_lib.render(oracle, packed, rp, threads=8, flags=oracle_lib.mirror_flags(st.as_dict()))
             assert (part.cpu().numpy().reshape(h, w, 4).view(np.uint32) == o_accum.view(np.uint32)).all(), r
             assert (ids.cpu().numpy().view(np.uint32).reshape(h, w) == o_ids).all()
             assert st.paths == o_st["paths"] and st.rays == o_st["rays"] and st.node_visits == o_st["node_visits"]

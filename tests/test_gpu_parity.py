@@ -41,7 +41,7 @@ def compare(renderer, oracle, scene, w, h, spp, seed, rank=0, num_ranks=1, rows=
     assert not mism.any(), f"{mism.any(axis=-1).sum()} pixels differ; first {np.argwhere(mism)[:3]}"
     assert (rgba[sl] == o_rgba[sl]).all()
     if rows is None:
-        o_st = oracle_lib.render(oracle, packed, rp, threads=8, flags=oracle_lib.mirror_flags(st["scene_in_lds"]))[3]
+        o_st = oracle_lib.render(oracle, packed, rp, threads=8, flags=oracle_lib.mirror_flags(st))[3]
         for k in COUNTERS:
             assert st[k] == o_st[k], (k, st[k], o_st[k])
     return st
