@@ -374,6 +374,8 @@ typedef struct {
   int any_hit_shadows; /* ORC_FLAG_ANYHIT_OPAQUE_SHADOW and the scene is provably all-opaque */
   int cull_behind;     /* ORC_FLAG_CULL_BEHIND: skip boxes with t_far < 0 (checker mirror of the HIP path) */
   int self_first;      /* ORC_FLAG_SELF_FIRST: any-hit shadow queries test the shading point's own triangle first (checker mirror of the HIP path) */
+  const pt_scene_desc* probe; /* ORC_FLAG_TRANSPARENT_PROBE: a scene holding ONLY the triangles that are not provably opaque, under a tree of their own (orc_render_ex); NULL: off */
+  int probe_self_first, probe_span_order; /* the all-opaque checker modes, applied to the shadow queries the probe clears */
   int stale_skip;      /* ORC_FLAG_STALE_SKIP: closest-hit walks of path rays skip deferred inner nodes whose entry distance is no longer below the hit (checker mirror) */
   int span_order;      /* ORC_FLAG_ANYHIT_SPAN_ORDER: any-hit walks enter the child the ray stays inside longer first (checker mirror of the HIP path) */
   uint32_t self_tri;   /* the triangle the current vertex lies on */
@@ -705,6 +707,37 @@ static void ray_scene_intersect(shctx* c, const ray_t* ray, isect_t* info) {
   ray_scene_intersect_ex(c, ray, info, 0);
 }
 
+/* The shadow query of a ray that can only meet opaque surfaces: any accepted triangle decides (0), none lets the sample through (1).
+ * target_tri (checker mode only, ORC_NO_HIT = none): the emissive triangle an area-light sample aims at, tested first; then
+ * (self_first) the triangle the shading point lies on; then the any-hit walk. */
+static float any_hit_shadow_query(shctx* c, const ray_t* rayp, isect_t* info, uint32_t target_tri, int self_first) {
+  const ray_t ray = *rayp;
+  info->t = ORC_INFINITY;
+  info->tri_idx = ORC_NO_HIT;
+  if (target_tri != ORC_NO_HIT) {
+    ray_triangle_intersect(c, &ray, target_tri, info);
+    if (info->tri_idx != ORC_NO_HIT) {
+      ++c->st.rays;
+      ++c->st.rays_shadow_shortcut;
+      return 0.0f;
+    }
+  }
+  if (self_first && c->self_tri != ORC_NO_HIT && c->self_tri != target_tri) {
+    /* a light on the far side of the surface: the ray starts NORMAL_DELTA above the triangle it stands on and goes through it */
+    ray_triangle_intersect(c, &ray, c->self_tri, info);
+    if (info->tri_idx != ORC_NO_HIT) {
+      ++c->st.rays;
+      ++c->st.rays_shadow_shortcut;
+      return 0.0f;
+    }
+  }
+  ++c->st.rays_shadow_walked;
+  c->in_shadow_walk = 1;
+  ray_scene_intersect_ex(c, &ray, info, 1);
+  c->in_shadow_walk = 0;
+  return info->tri_idx == ORC_NO_HIT ? 1.0f : 0.0f;
+}
+
 /* main.comp:306-332 */
 /* target_tri (checker mode only, ORC_NO_HIT = none): the emissive triangle an area-light sample
  * aims at.  In the all-opaque any-hit mode the HIP path tests that triangle first — if the ray
@@ -713,31 +746,25 @@ static void ray_scene_intersect(shctx* c, const ray_t* ray, isect_t* info) {
 static float ray_scene_intersect_with_transparency(shctx* c, ray_t ray, isect_t* info, uint32_t target_tri) {
   float transparency = 1.0f;
   uint32_t step = 0;
-  if (c->any_hit_shadows) { /* every surface has alpha == 1: the first closest hit returns 0 (main.comp:325) */
-    info->t = ORC_INFINITY;
-    info->tri_idx = ORC_NO_HIT;
-    if (target_tri != ORC_NO_HIT) {
-      ray_triangle_intersect(c, &ray, target_tri, info);
-      if (info->tri_idx != ORC_NO_HIT) {
-        ++c->st.rays;
-        ++c->st.rays_shadow_shortcut;
-        return 0.0f;
-      }
-    }
-    if (c->self_first && c->self_tri != ORC_NO_HIT && c->self_tri != target_tri) {
-      /* a light on the far side of the surface: the ray starts NORMAL_DELTA above the triangle it stands on and goes through it */
-      ray_triangle_intersect(c, &ray, c->self_tri, info);
-      if (info->tri_idx != ORC_NO_HIT) {
-        ++c->st.rays;
-        ++c->st.rays_shadow_shortcut;
-        return 0.0f;
-      }
-    }
-    ++c->st.rays_shadow_walked;
+  if (c->any_hit_shadows) return any_hit_shadow_query(c, &ray, info, target_tri, c->self_first); /* every surface has alpha == 1: the first closest hit returns 0 (main.comp:325) */
+  if (c->probe) {
+    /* checker mirror of the HIP path's probe (ORC_FLAG_TRANSPARENT_PROBE). The reference's answer depends on alpha only at hits on
+     * triangles that are not provably opaque. If the ray is accepted by NONE of them — an any-hit walk of the small tree that holds
+     * only those — every hit of the reference's walk is opaque: its first closest hit returns 0, no hit returns 1, exactly what the
+     * all-opaque any-hit query gives. Otherwise: the reference's walk below. Probe visits and tests are counted, it is no ray. */
+    const pt_scene_desc* scene = c->sc;
+    const int span = c->span_order;
+    isect_t pi;
+    pi.t = ORC_INFINITY; pi.u = pi.v = 0.0f; pi.tri_idx = ORC_NO_HIT;
+    c->sc = c->probe;
+    c->span_order = 0; /* (the HIP path's merged loop enters the nearer child first in every walk of such a scene) */
     c->in_shadow_walk = 1;
-    ray_scene_intersect_ex(c, &ray, info, 1);
+    ray_scene_intersect_ex(c, &ray, &pi, 1);
     c->in_shadow_walk = 0;
-    return info->tri_idx == ORC_NO_HIT ? 1.0f : 0.0f;
+    --c->st.rays;
+    c->sc = scene;
+    c->span_order = span;
+    if (pi.tri_idx == ORC_NO_HIT) return any_hit_shadow_query(c, &ray, info, target_tri, c->probe_self_first); /* (its walk enters the nearer child first, as every walk of such a scene does in the HIP path's merged loop; only the probe's own walk takes ORC_FLAG_ANYHIT_SPAN_ORDER) */
   }
   while (step < ORC_MAX_TRANSPARENCY_STEPS) {
     ++step;
@@ -1110,6 +1137,8 @@ typedef struct {
   int span_order;
   int stale_skip;
   const uint8_t* mat_opaque;
+  const pt_scene_desc* probe;
+  int probe_self_first, probe_span_order;
   pt_stats st;
 } worker_arg;
 
@@ -1124,6 +1153,9 @@ static void* worker_main(void* p) {
   c.self_first = w->self_first;
   c.span_order = w->span_order;
   c.stale_skip = w->stale_skip;
+  c.probe = w->probe;
+  c.probe_self_first = w->probe_self_first;
+  c.probe_span_order = w->probe_span_order;
   c.mat_opaque = w->mat_opaque;
   c.self_tri = ORC_NO_HIT;
   c.stack = (uint32_t*)malloc(sizeof(uint32_t) * (w->sc->bvh_max_depth + 64)); /* main.comp:263-265 */
@@ -1182,11 +1214,57 @@ int orc_render_ex(const pt_scene_desc* scene, const pt_render_params* params, ui
   volatile uint32_t next_row = 0; /* next 32-pixel chunk of the band */
   const int any_hit = (flags & ORC_FLAG_ANYHIT_OPAQUE_SHADOW) && orc_scene_all_opaque(scene);
   uint8_t* mat_opaque = NULL;
-  if ((flags & ORC_FLAG_OPAQUE_TRIANGLES) && !any_hit) {
+  if ((flags & (ORC_FLAG_OPAQUE_TRIANGLES | ORC_FLAG_TRANSPARENT_PROBE)) && !any_hit) {
     uint8_t* memo = (uint8_t*)calloc(scene->image_count ? scene->image_count : 1, 1);
     mat_opaque = (uint8_t*)calloc(scene->material_count, 1);
     for (uint32_t i = 0; i < scene->material_count; ++i) mat_opaque[i] = (uint8_t)material_provably_opaque(scene, &scene->materials[i], memo);
     free(memo);
+  }
+  /* ORC_FLAG_TRANSPARENT_PROBE: the triangles that are not provably opaque, in scene order, under a tree of their own built by the
+   * same builder (so that the HIP path, which builds it with pt_build_bvh, walks the same nodes). Off when there is no such
+   * triangle (the scene is all-opaque) or the tree is deeper than the traversal stack allows. */
+  pt_scene_desc probe_scene;
+  float* probe_pos = NULL;
+  pt_packed_bvh_node* probe_nodes = NULL;
+  int have_probe = 0;
+  if ((flags & ORC_FLAG_TRANSPARENT_PROBE) && !any_hit && mat_opaque) {
+    uint32_t n = 0;
+    for (uint32_t t = 0; t < scene->triangle_count; ++t)
+      if (!mat_opaque[scene->packed_vertex_data[3 * (size_t)t].material_index]) ++n;
+    if (n > 0) {
+      pt_vertex* pv = (pt_vertex*)calloc(3 * (size_t)n, sizeof(pt_vertex));
+      uint32_t* ptri = (uint32_t*)malloc(3 * (size_t)n * sizeof(uint32_t));
+      pt_bvh_node* pn = (pt_bvh_node*)malloc(2 * (size_t)n * sizeof(pt_bvh_node));
+      uint32_t k = 0, node_count = 0, depth = 0;
+      for (uint32_t t = 0; t < scene->triangle_count; ++t) {
+        if (mat_opaque[scene->packed_vertex_data[3 * (size_t)t].material_index]) continue;
+        for (int v = 0; v < 3; ++v) {
+          memcpy(pv[3 * (size_t)k + v].position, scene->vertex_positions + 12 * (size_t)t + 4 * v, 12);
+          ptri[3 * (size_t)k + v] = 3 * k + v;
+        }
+        ++k;
+      }
+      orc_build_bvh(pv, 3 * n, ptri, n, 16, pn, &node_count, &depth);
+      if (depth <= scene->bvh_max_depth + 32) {
+        probe_pos = (float*)calloc(12 * (size_t)n, sizeof(float));
+        probe_nodes = (pt_packed_bvh_node*)calloc(node_count, sizeof(pt_packed_bvh_node));
+        for (uint32_t t = 0; t < n; ++t)
+          for (int v = 0; v < 3; ++v) memcpy(probe_pos + 12 * (size_t)t + 4 * v, pv[ptri[3 * (size_t)t + v]].position, 12);
+        for (uint32_t i = 0; i < node_count; ++i) { /* render_job.cc:107-120 */
+          memcpy(probe_nodes[i].aabb_min, pn[i].aabb_min, 12);
+          memcpy(probe_nodes[i].aabb_max, pn[i].aabb_max, 12);
+          probe_nodes[i].triangle_count = pn[i].triangle_count;
+          probe_nodes[i].left_or_begin = pn[i].triangle_count > 0 ? pn[i].begin_index : pn[i].left_child_index;
+        }
+        probe_scene = *scene;
+        probe_scene.vertex_positions = probe_pos;
+        probe_scene.bvh_nodes = probe_nodes;
+        probe_scene.bvh_node_count = node_count;
+        probe_scene.triangle_count = n;
+        have_probe = 1;
+      }
+      free(pv); free(ptri); free(pn);
+    }
   }
   pthread_t th[256];
   worker_arg args[256];
@@ -1200,7 +1278,10 @@ int orc_render_ex(const pt_scene_desc* scene, const pt_render_params* params, ui
     w->self_first = any_hit && (flags & ORC_FLAG_SELF_FIRST) != 0;
     w->span_order = any_hit && (flags & ORC_FLAG_ANYHIT_SPAN_ORDER) != 0;
     w->stale_skip = (flags & ORC_FLAG_STALE_SKIP) != 0;
-    w->mat_opaque = mat_opaque;
+    w->mat_opaque = (flags & ORC_FLAG_OPAQUE_TRIANGLES) ? mat_opaque : NULL;
+    w->probe = have_probe ? &probe_scene : NULL;
+    w->probe_self_first = have_probe && (flags & ORC_FLAG_SELF_FIRST) != 0;
+    w->probe_span_order = have_probe && (flags & ORC_FLAG_ANYHIT_SPAN_ORDER) != 0;
     if (num_threads > 1) pthread_create(&th[i], NULL, worker_main, w);
     else worker_main(w);
   }
@@ -1221,6 +1302,8 @@ int orc_render_ex(const pt_scene_desc* scene, const pt_render_params* params, ui
     total.rays_shadow_shortcut += args[i].st.rays_shadow_shortcut;
   }
   free(mat_opaque);
+  free(probe_pos);
+  free(probe_nodes);
   if (stats_out) *stats_out = total;
   return 0;
 }

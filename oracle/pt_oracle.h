@@ -64,6 +64,13 @@ int orc_render(const pt_scene_desc* scene, const pt_render_params* params, uint8
  * slab arithmetic is monotonic in the bounds, so both would be culled); node_visits shrinks by 4-5 %. A MODEL and the checker
  * mirror of a kernel that was built in round 3 and measured slower: no shipped HIP kernel sets it. */
 #define ORC_FLAG_STALE_SKIP 32u
+/* ORC_FLAG_TRANSPARENT_PROBE (scenes that are NOT all-opaque): the triangles that are not provably opaque get a small tree of their
+ * own; a shadow ray that none of them accepts (any-hit walk of that tree, counted in node_visits / tri_tests, not in rays) can only
+ * meet opaque surfaces, so the query is the all-opaque one — the emitter triangle first, with ORC_FLAG_SELF_FIRST the shading point's
+ * own triangle, then an any-hit walk. A ray that one of them does accept takes the reference's walk. Same image by construction;
+ * node visits x 0.53 on cfg3. A MODEL and the checker mirror of kernels that were built in round 3 (three forms, all bit-identical to
+ * this mode, counters included) and measured 6-16 % slower on cfg3: no shipped HIP kernel sets it. */
+#define ORC_FLAG_TRANSPARENT_PROBE 64u
 int orc_render_ex(const pt_scene_desc* scene, const pt_render_params* params, uint8_t* rgba8_out,
                   float* accum_out, uint32_t* primary_id_out, pt_stats* stats_out, int num_threads,
                   uint32_t y_begin, uint32_t y_end, uint32_t flags);

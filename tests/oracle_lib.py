@@ -32,6 +32,7 @@ CULL_BEHIND = 2
 SELF_FIRST = 4
 ANYHIT_SPAN_ORDER = 8
 OPAQUE_TRIANGLES = 16
+TRANSPARENT_PROBE = 64  # model / mirror of the round-3 experiment kernels that cleared shadow queries of a not-all-opaque scene by a probe of its maybe-transparent triangles (exact; not shipped)
 STALE_SKIP = 32  # model / mirror of the round-3 experiment kernel that skipped stale inner stack entries (exact; node_visits shrinks; not shipped)
 # the checker modes that reproduce the HIP path's work counters (identical images by construction, tests/test_oracle_shader.py):
 GPU_MIRROR = ANYHIT_OPAQUE_SHADOW | CULL_BEHIND | SELF_FIRST | ANYHIT_SPAN_ORDER | OPAQUE_TRIANGLES  # scenes read from global memory
@@ -42,7 +43,7 @@ def mirror_flags(st):
     """Checker flags for a render whose pt_stats the HIP path reported (the stats dict; a bare scene_in_lds value is accepted too)."""
     if not isinstance(st, dict):
         return GPU_MIRROR_LDS if st else GPU_MIRROR
-    return (GPU_MIRROR_LDS if st["scene_in_lds"] else GPU_MIRROR) | (STALE_SKIP if st.get("stale_skip") else 0)
+    return GPU_MIRROR_LDS if st["scene_in_lds"] else GPU_MIRROR
 
 
 def render(lib, packed, rp, threads=8, rows=None, want_ids=True, flags=0):

@@ -94,6 +94,36 @@ def test_opaque_triangle_shortcut_gives_identical_images(oracle):
     assert saved > 0
 
 
+def test_transparent_probe_gives_identical_images(oracle):
+    """ORC_FLAG_TRANSPARENT_PROBE (scenes that are NOT all-opaque): a shadow ray that none of the maybe-transparent triangles accepts
+    is answered by the all-opaque query (emitter triangle first, own triangle first, any-hit walk). Frames, ids, rays, shaded hits and
+    texture taps stay those of the reference form; the walks shrink. (The kernels that did this were bit-identical to this mode on the
+    GPU, counters included, and SLOWER on cfg3 with half the node visits — the wave's time is its slowest lane's chain of dependent
+    fetches, and the unoccluded sun rays that make that chain cost an any-hit walk what they cost a closest-hit walk. Not shipped,
+    DESIGN.md section 5; the flag stays as the proof that the scheme is exact.)"""
+    M = oracle_lib
+    saved = total = used = 0
+    for s in [scenes.cornell_scene(True, True, True, True), scenes.textured_scene(), scenes.atrium_scene(detail=2, tex_size=32),
+              scenes.random_scene(7), scenes.random_scene(12), scenes.random_scene(21, with_punctual=False), scenes.random_scene(8, with_punctual=False)]:
+        p = PackedScene(s, oracle, "orc_")
+        if oracle.orc_scene_all_opaque(C.byref(p.desc)):
+            continue
+        used += 1
+        rp = p.render_params(oracle, 64, 48, 9, seed=37, prefix="orc_")
+        a = oracle_lib.render(oracle, p, rp)
+        b = oracle_lib.render(oracle, p, rp, flags=M.GPU_MIRROR)
+        for flags in (M.TRANSPARENT_PROBE, M.GPU_MIRROR | M.TRANSPARENT_PROBE):
+            c = oracle_lib.render(oracle, p, rp, flags=flags)
+            assert a[1].tobytes() == c[1].tobytes() and a[0].tobytes() == c[0].tobytes() and (a[2] == c[2]).all()
+            for k in ("paths", "rays", "rays_closest", "shaded_vertices", "nan_samples"):
+                assert a[3][k] == c[3][k], k
+            assert c[3]["rays_shadow_walked"] + c[3]["rays_shadow_shortcut"] == a[3]["rays_shadow_walked"]
+        assert c[3]["hits_shaded"] <= b[3]["hits_shaded"] and c[3]["texture_taps"] <= b[3]["texture_taps"]
+        saved += b[3]["node_visits"] - c[3]["node_visits"]
+        total += b[3]["node_visits"]
+    assert used >= 4 and saved > 0.1 * total, (used, saved, total)
+
+
 def test_stale_entry_skip_gives_identical_images(oracle):
     """ORC_FLAG_STALE_SKIP: a closest-hit walk of a path ray does not visit a deferred inner node whose entry distance (rounded down
     to bfloat16) is no longer below the closest hit. Its children lie inside its box and would both be culled, so frames, ids and
