@@ -11,8 +11,11 @@ _lib = None
 def load():
     global _lib
     if _lib is None:
-        src = os.path.join(ROOT, "oracle", "pt_oracle.c")
-        if not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        # (every file the library is compiled from: the oracle shares pt_stats and the arithmetic header with the product, and a
+        # library built against another pt_stats writes past the caller's struct)
+        deps = [os.path.join(ROOT, "oracle", "pt_oracle.c"), os.path.join(ROOT, "oracle", "pt_oracle.h"), os.path.join(ROOT, "oracle", "Makefile"),
+                os.path.join(ROOT, "include", "pathtracer_amd.h"), os.path.join(ROOT, "include", "pt_glsl_math.h")]
+        if not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(d) for d in deps if os.path.exists(d)):
             subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
         _lib = C.CDLL(_SO)
         _lib.orc_triple32.restype = C.c_uint32
